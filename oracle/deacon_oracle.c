@@ -1,0 +1,790 @@
+/*
+ * deacon_oracle.c -- CPU restatement of the Deacon read-filtering hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it, and
+ * only as the checker.  The product path (deacon-server_amd/csrc) never links,
+ * imports or calls this file.
+ *
+ * PARITY STATUS: "parity unpinned" at value level.  The reference is Rust
+ * (crate deacon 0.10.0) and cannot be compiled here (no cargo/rustc); its hot-path
+ * arithmetic lives in third-party crates that are not under /root/reference:
+ *   simd-minimizers 1.3.0, packed-seq 3.2.1, xxhash-rust 0.8.15,
+ *   rustc-hash 2.1.1 / hashbrown 0.15.5, bincode 2.0.1        (Cargo.lock)
+ * This file restates their published algorithms and is
+ * anchored on the reference's own call sites and behavioural tests:
+ *   - XXH3-64 (8 / 16 byte inputs) is checked bit-for-bit against the independent C xxHash
+ *     (python `xxhash`) in tests/test_oracle.py -> pinned.
+ *   - A2/A4/A6/A9 (2-bit code, ntHash32 canonical minimizer rule, k-mer value, bincode
+ *     varint) are pinned only by the reference's behavioural tests (constraint suite
+ *     C-1..C-11, tests/test_reference_constraints.py) -> unpinned at value level.
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define DOR_OK 0
+#define DOR_ERR_ARG (-1)
+#define DOR_ERR_CAP (-2)
+#define DOR_ERR_IO (-3)
+#define DOR_ERR_FORMAT (-4)
+#define DOR_ERR_NOMEM (-5)
+
+typedef unsigned __int128 u128;
+
+/* ------------------------------------------------------------------------------------------
+ * XXH3-64, seed 0, default secret, for the only two input sizes the path uses.
+ * Follows the XXH3 specification (len 4..8 and 9..16 branches); the reference calls
+ * xxhash_rust::xxh3::xxh3_64(&kmer.to_le_bytes()) at src/filter_common.rs:296,305 and
+ * src/minimizers.rs:179,188.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
+
+/* kSecret bytes 8..23, 24..39, 40..55 of the XXH3 default secret, pre-combined. */
+#define XXH3_BITFLIP_4TO8 0xC73AB174C5ECD5A2ULL  /* secret[8..16) ^ secret[16..24) */
+#define XXH3_BITFLIP_LO 0x6782737BEA4239B9ULL    /* secret[24..32) ^ secret[32..40) */
+#define XXH3_BITFLIP_HI 0xAF56BC3B0996523AULL    /* secret[40..48) ^ secret[48..56) */
+#define XXH_PRIME_MX1 0x165667919E3779F9ULL
+#define XXH_PRIME_MX2 0x9FB21C651E98DF25ULL
+
+uint64_t dor_xxh3_64_u64(uint64_t v) {
+    /* XXH3_len_4to8_64b with len == 8: input64 = hi32 + (lo32 << 32) = rotl(v, 32). */
+    uint64_t x = rotl64(v, 32) ^ XXH3_BITFLIP_4TO8;
+    /* XXH3_rrmxmx(x, 8) */
+    x ^= rotl64(x, 49) ^ rotl64(x, 24);
+    x *= XXH_PRIME_MX2;
+    x ^= (x >> 35) + 8;
+    x *= XXH_PRIME_MX2;
+    return x ^ (x >> 28);
+}
+
+uint64_t dor_xxh3_64_u128(uint64_t v_lo, uint64_t v_hi) {
+    /* XXH3_len_9to16_64b with len == 16. */
+    uint64_t lo = v_lo ^ XXH3_BITFLIP_LO;
+    uint64_t hi = v_hi ^ XXH3_BITFLIP_HI;
+    u128 prod = (u128)lo * (u128)hi;
+    uint64_t acc = 16 + bswap64(lo) + hi + ((uint64_t)prod ^ (uint64_t)(prod >> 64));
+    /* XXH3_avalanche */
+    acc ^= acc >> 37;
+    acc *= XXH_PRIME_MX1;
+    return acc ^ (acc >> 32);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A2: 2-bit code.  packed-seq 3.2.1 `PackedSeqVec::from_ascii` (called at
+ * src/filter_common.rs:238): every byte c -> (c >> 1) & 3, i.e. A=0 C=1 T=2 G=3; non-ACGT bytes
+ * are mapped the same lossy way and still take part in hashing/min selection.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint32_t code_of(uint8_t c) { return (uint32_t)(c >> 1) & 3u; }
+
+/* A3: `matches!(b, A|C|G|T|a|c|g|t)` at src/filter_common.rs:254 (also src/minimizers.rs:9-14). */
+static inline int is_acgt(uint8_t c) {
+    switch (c) {
+    case 'A': case 'C': case 'G': case 'T':
+    case 'a': case 'c': case 'g': case 't':
+        return 1;
+    default:
+        return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4: canonical minimizer positions, restating simd-minimizers 1.3.0
+ * `canonical_minimizer_positions` (called at src/filter_common.rs:261-267, src/minimizers.rs:143-148).
+ *   ntHash32:  fw(j) = XOR_i rotl32(F[x_{j+i}], k-1-i),  rc(j) = XOR_i rotl32(F[x_{j+i}^2], i),
+ *              h(j) = fw + rc (wrapping)
+ *   F = low 32 bits of the classic ntHash seeds listed in A,C,G,T order, indexed by 2-bit code.
+ *   Only h>>16 is compared.  Window i (k-mers i..i+w-1, chars i..i+l-1, l=k+w-1 odd) is
+ *   "canonical" iff 2*#{chars with code&2} > l: canonical -> leftmost minimal k-mer, else
+ *   rightmost minimal k-mer.  Output: selected positions with consecutive duplicates removed.
+ * ---------------------------------------------------------------------------------------- */
+static const uint32_t NT_F[4] = {0x95c60474u, 0x62a02b4cu, 0x82572324u, 0x4be24456u};
+
+static inline uint32_t rotl32(uint32_t x, unsigned r) {
+    r &= 31u;
+    return r ? (x << r) | (x >> (32 - r)) : x;
+}
+
+/* Direct-from-definition form (O(n*k + n*w)); used to cross-check the rolling form below. */
+int64_t dor_canonical_minimizer_positions_naive(const uint8_t *codes, uint64_t n, uint32_t k,
+                                                uint32_t w, uint32_t *out, uint64_t cap) {
+    if (k == 0 || w == 0) return DOR_ERR_ARG;
+    uint64_t l = (uint64_t)k + w - 1;
+    if ((l & 1) == 0) return DOR_ERR_ARG; /* simd-minimizers asserts l odd; index.rs:186-194 */
+    if (n < l) return 0;
+    uint64_t nk = n - k + 1;
+    uint32_t *h = (uint32_t *)malloc(nk * sizeof(uint32_t));
+    if (!h) return DOR_ERR_NOMEM;
+    for (uint64_t j = 0; j < nk; ++j) {
+        uint32_t fw = 0, rc = 0;
+        for (uint32_t i = 0; i < k; ++i) {
+            uint32_t c = codes[j + i];
+            fw ^= rotl32(NT_F[c], k - 1 - i);
+            rc ^= rotl32(NT_F[c ^ 2u], i);
+        }
+        h[j] = fw + rc;
+    }
+    uint64_t cnt = 0;
+    int have_prev = 0;
+    uint32_t prev = 0;
+    for (uint64_t i = 0; i + l <= n; ++i) {
+        uint64_t tg = 0;
+        for (uint64_t t = i; t < i + l; ++t) tg += (codes[t] >> 1) & 1u;
+        int canonical = 2 * tg > l;
+        uint64_t best = i;
+        uint32_t bh = h[i] >> 16;
+        for (uint64_t j = i + 1; j < i + w; ++j) {
+            uint32_t hj = h[j] >> 16;
+            if (canonical ? (hj < bh) : (hj <= bh)) {
+                bh = hj;
+                best = j;
+            }
+        }
+        if (!have_prev || prev != (uint32_t)best) {
+            if (cnt >= cap) {
+                free(h);
+                return DOR_ERR_CAP;
+            }
+            out[cnt++] = (uint32_t)best;
+            prev = (uint32_t)best;
+            have_prev = 1;
+        }
+    }
+    free(h);
+    return (int64_t)cnt;
+}
+
+/* Rolling form (O(n*w) worst case, O(n) typical): rolling ntHash, rolling TG count, and a
+ * rescan-on-expiry sliding minimum.  Same results as the naive form (tests cross-check). */
+int64_t dor_canonical_minimizer_positions(const uint8_t *codes, uint64_t n, uint32_t k,
+                                          uint32_t w, uint32_t *out, uint64_t cap) {
+    if (k == 0 || w == 0) return DOR_ERR_ARG;
+    uint64_t l = (uint64_t)k + w - 1;
+    if ((l & 1) == 0) return DOR_ERR_ARG;
+    if (n < l) return 0;
+    uint64_t nk = n - k + 1;
+    uint16_t *h = (uint16_t *)malloc(nk * sizeof(uint16_t)); /* only the top 16 bits matter */
+    if (!h) return DOR_ERR_NOMEM;
+    uint32_t f_rot[4], c_tab[4], c_rot[4];
+    for (int c = 0; c < 4; ++c) {
+        f_rot[c] = rotl32(NT_F[c], k - 1);
+        c_tab[c] = NT_F[c ^ 2];
+        c_rot[c] = rotl32(NT_F[c ^ 2], k - 1);
+    }
+    uint32_t fw = 0, rc = 0;
+    for (uint32_t i = 0; i + 1 < k; ++i) {
+        uint32_t c = codes[i];
+        fw = rotl32(fw, 1) ^ NT_F[c];
+        rc = rotl32(rc, 31) ^ c_rot[c];
+    }
+    for (uint64_t j = 0; j < nk; ++j) {
+        uint32_t a = codes[j + k - 1], r = codes[j];
+        uint32_t fw_out = rotl32(fw, 1) ^ NT_F[a];
+        uint32_t rc_out = rotl32(rc, 31) ^ c_rot[a];
+        h[j] = (uint16_t)((fw_out + rc_out) >> 16);
+        fw = fw_out ^ f_rot[r];
+        rc = rc_out ^ c_tab[r];
+    }
+    uint64_t tg = 0;
+    for (uint64_t t = 0; t + 1 < l; ++t) tg += (codes[t] >> 1) & 1u;
+    uint64_t cnt = 0;
+    int have_prev = 0;
+    uint32_t prev = 0;
+    /* lbest/rbest: cached leftmost / rightmost arg-min of the current window. */
+    uint64_t lbest = 0, rbest = 0;
+    int valid = 0;
+    for (uint64_t i = 0; i + l <= n; ++i) {
+        tg += (codes[i + l - 1] >> 1) & 1u;
+        if (!valid || lbest < i || rbest < i) {
+            lbest = rbest = i;
+            for (uint64_t j = i + 1; j < i + w; ++j) {
+                if (h[j] < h[lbest]) lbest = j;
+                if (h[j] <= h[rbest]) rbest = j;
+            }
+            valid = 1;
+        } else {
+            uint64_t j = i + w - 1;
+            if (h[j] < h[lbest]) lbest = j;
+            if (h[j] <= h[rbest]) rbest = j;
+        }
+        uint64_t best = (2 * tg > l) ? lbest : rbest;
+        tg -= (codes[i] >> 1) & 1u;
+        if (!have_prev || prev != (uint32_t)best) {
+            if (cnt >= cap) {
+                free(h);
+                return DOR_ERR_CAP;
+            }
+            out[cnt++] = (uint32_t)best;
+            prev = (uint32_t)best;
+            have_prev = 1;
+        }
+    }
+    free(h);
+    return (int64_t)cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6: canonical k-mer value, restating simd-minimizers `iter_canonical_minimizer_values[_u128]`
+ * + packed-seq `read_kmer` / `read_revcomp_kmer` (called at src/filter_common.rs:289-307):
+ * a = k-mer with base i at bits 2i; b = reverse complement in the same encoding; v = min(a, b).
+ * ---------------------------------------------------------------------------------------- */
+static inline u128 kmer_value(const uint8_t *codes, uint32_t k) {
+    u128 a = 0, b = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        u128 c = codes[i];
+        a |= c << (2 * i);
+        b |= (c ^ 2) << (2 * (k - 1 - i));
+    }
+    return a < b ? a : b;
+}
+
+uint64_t dor_kmer_hash(const uint8_t *codes, uint32_t k) {
+    u128 v = kmer_value(codes, k);
+    /* src/filter_common.rs:289: `if kmer_length > 32` -> u128 / 16-byte hash, else u64 / 8-byte */
+    if (k > 32) return dor_xxh3_64_u128((uint64_t)v, (uint64_t)(v >> 64));
+    return dor_xxh3_64_u64((uint64_t)v);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A1-A6: src/filter_common.rs:211-310 `get_minimizer_hashes_and_positions`.
+ * Returns the number of minimizers (after the ACGT filter), writes hashes/positions.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dor_minimizer_hashes_and_positions(const uint8_t *seq, uint64_t len, uint64_t prefix_length,
+                                           uint32_t k, uint32_t w, uint64_t *out_hashes,
+                                           uint32_t *out_pos, uint64_t cap) {
+    if (k == 0 || w == 0) return DOR_ERR_ARG;
+    if (len < k) return 0; /* :217 -- checked on the full read, before the prefix cut */
+    uint64_t n = len;
+    if (prefix_length > 0 && len > prefix_length) n = prefix_length; /* :222-226 */
+    if (n > 0 && seq[n - 1] == '\n') n -= 1;                         /* :229 */
+    if (k > 56) return DOR_ERR_ARG;                                  /* :269-272 assert */
+    uint64_t l = (uint64_t)k + w - 1;
+    if ((l & 1) == 0) return DOR_ERR_ARG;
+    if (n < l) return 0;
+    uint8_t *codes = (uint8_t *)malloc(n);
+    uint32_t *pos = (uint32_t *)malloc((n - l + 1) * sizeof(uint32_t));
+    if (!codes || !pos) {
+        free(codes);
+        free(pos);
+        return DOR_ERR_NOMEM;
+    }
+    for (uint64_t i = 0; i < n; ++i) codes[i] = (uint8_t)code_of(seq[i]); /* :238 */
+    int64_t np = dor_canonical_minimizer_positions(codes, n, k, w, pos, n - l + 1); /* :261 */
+    if (np < 0) {
+        free(codes);
+        free(pos);
+        return np;
+    }
+    uint64_t cnt = 0;
+    for (int64_t e = 0; e < np; ++e) {
+        uint32_t p = pos[e];
+        int ok = 1; /* :275-286 -- keep iff mask bits p..p+k are all zero */
+        for (uint32_t i = 0; i < k; ++i)
+            if (!is_acgt(seq[p + i])) {
+                ok = 0;
+                break;
+            }
+        if (!ok) continue;
+        if (cnt >= cap) {
+            free(codes);
+            free(pos);
+            return DOR_ERR_CAP;
+        }
+        out_hashes[cnt] = dor_kmer_hash(codes + p, k); /* :289-307 */
+        if (out_pos) out_pos[cnt] = p;
+        cnt++;
+    }
+    free(codes);
+    free(pos);
+    return (int64_t)cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A11: index-side variant, src/minimizers.rs:125-191 `fill_minimizer_hashes`.
+ * ---------------------------------------------------------------------------------------- */
+static inline uint8_t canonicalise_nucleotide(uint8_t c) { /* src/minimizers.rs:24-43 */
+    switch (c) {
+    case 'A': case 'a': return 'A';
+    case 'C': case 'c': return 'C';
+    case 'G': case 'g': return 'G';
+    case 'T': case 't': return 'T';
+    case 'R': case 'r': return 'G';
+    case 'Y': case 'y': return 'C';
+    case 'S': case 's': return 'G';
+    case 'W': case 'w': return 'A';
+    case 'K': case 'k': return 'G';
+    case 'M': case 'm': return 'C';
+    case 'B': case 'b': return 'C';
+    case 'D': case 'd': return 'G';
+    case 'H': case 'h': return 'C';
+    case 'V': case 'v': return 'G';
+    case 'N': case 'n': return 'C';
+    default: return 'C';
+    }
+}
+
+uint8_t dor_canonicalise_nucleotide(uint8_t c) { return canonicalise_nucleotide(c); }
+
+float dor_scaled_entropy(const uint8_t *kmer, uint32_t k) { /* src/minimizers.rs:73-121 */
+    if (k < 10) return 1.0f;
+    uint8_t counts[4] = {0, 0, 0, 0};
+    uint8_t total = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        switch (kmer[i]) {
+        case 'A': case 'a': counts[0]++; total++; break;
+        case 'C': case 'c': counts[1]++; total++; break;
+        case 'G': case 'g': counts[2]++; total++; break;
+        case 'T': case 't': counts[3]++; total++; break;
+        default: break;
+        }
+    }
+    if (total == 0) return 1.0f;
+    float tf = (float)total, entropy = 0.0f;
+    for (int i = 0; i < 4; ++i)
+        if (counts[i] > 0) {
+            float p = (float)counts[i] / tf;
+            entropy -= p * log2f(p);
+        }
+    return entropy / 2.0f;
+}
+
+int64_t dor_index_minimizer_hashes(const uint8_t *seq, uint64_t len, uint32_t k, uint32_t w,
+                                   float entropy_threshold, uint64_t *out_hashes, uint64_t cap) {
+    if (k == 0 || w == 0) return DOR_ERR_ARG;
+    if (len < k) return 0; /* :135 */
+    uint64_t l = (uint64_t)k + w - 1;
+    if ((l & 1) == 0) return DOR_ERR_ARG;
+    if (len < l) return 0;
+    uint8_t *codes = (uint8_t *)malloc(len);
+    uint32_t *pos = (uint32_t *)malloc((len - l + 1) * sizeof(uint32_t));
+    if (!codes || !pos) {
+        free(codes);
+        free(pos);
+        return DOR_ERR_NOMEM;
+    }
+    for (uint64_t i = 0; i < len; ++i) codes[i] = (uint8_t)code_of(canonicalise_nucleotide(seq[i]));
+    int64_t np = dor_canonical_minimizer_positions(codes, len, k, w, pos, len - l + 1); /* :143 */
+    if (np < 0) {
+        free(codes);
+        free(pos);
+        return np;
+    }
+    uint64_t cnt = 0;
+    for (int64_t e = 0; e < np; ++e) {
+        uint32_t p = pos[e];
+        int ok = 1; /* :151-160 -- ACGT test on the ORIGINAL bytes */
+        for (uint32_t i = 0; i < k; ++i)
+            if (!is_acgt(seq[p + i])) {
+                ok = 0;
+                break;
+            }
+        if (!ok) continue;
+        if (entropy_threshold != 0.0f && dor_scaled_entropy(seq + p, k) < entropy_threshold) continue;
+        if (cnt >= cap) {
+            free(codes);
+            free(pos);
+            return DOR_ERR_CAP;
+        }
+        out_hashes[cnt++] = dor_kmer_hash(codes + p, k); /* :172-190 */
+    }
+    free(codes);
+    free(pos);
+    return (int64_t)cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7: thresholds, src/filter_common.rs:84-112.
+ * ---------------------------------------------------------------------------------------- */
+uint64_t dor_required_hits(uint64_t abs_threshold, double rel_threshold, uint64_t total) {
+    uint64_t rel_required = 0;
+    if (total != 0) {
+        double r = round(rel_threshold * (double)total); /* f64::round: half away from zero */
+        /* Rust `as usize`: saturating, NaN -> 0 */
+        if (!(r > 0.0)) rel_required = 0;
+        else if (r >= 18446744073709551616.0) rel_required = UINT64_MAX;
+        else rel_required = (uint64_t)r;
+        if (rel_required < 1) rel_required = 1; /* .max(1) */
+    }
+    return abs_threshold > rel_required ? abs_threshold : rel_required;
+}
+
+int dor_meets_filtering_criteria(uint64_t hits, uint64_t total, uint64_t abs_threshold,
+                                 double rel_threshold, int deplete) {
+    uint64_t required = dor_required_hits(abs_threshold, rel_threshold, total);
+    return deplete ? (hits < required) : (hits >= required);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Exact u64 set (stands in for FxHashSet<u64>; only membership is ever observed on the filter
+ * path -- src/filter_common.rs:144,185; src/index.rs:98-105).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dor_set {
+    uint64_t *slots;
+    uint64_t mask;
+    uint64_t count;
+    int has_zero;
+} dor_set;
+
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    return x;
+}
+
+dor_set *dor_set_new(uint64_t expected) {
+    dor_set *s = (dor_set *)calloc(1, sizeof(dor_set));
+    if (!s) return NULL;
+    uint64_t cap = 16;
+    while (cap < expected * 2 + 2) cap <<= 1;
+    s->slots = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    if (!s->slots) {
+        free(s);
+        return NULL;
+    }
+    s->mask = cap - 1;
+    return s;
+}
+
+void dor_set_free(dor_set *s) {
+    if (s) {
+        free(s->slots);
+        free(s);
+    }
+}
+
+static int dor_set_grow(dor_set *s);
+
+/* returns 1 if newly inserted, 0 if already present, <0 on error */
+int dor_set_insert(dor_set *s, uint64_t key) {
+    if (key == 0) {
+        int fresh = !s->has_zero;
+        s->has_zero = 1;
+        s->count += (uint64_t)fresh;
+        return fresh;
+    }
+    if ((s->count + 1) * 2 > s->mask + 1)
+        if (dor_set_grow(s) != 0) return DOR_ERR_NOMEM;
+    uint64_t i = mix64(key) & s->mask;
+    for (;;) {
+        uint64_t cur = s->slots[i];
+        if (cur == key) return 0;
+        if (cur == 0) {
+            s->slots[i] = key;
+            s->count++;
+            return 1;
+        }
+        i = (i + 1) & s->mask;
+    }
+}
+
+static int dor_set_grow(dor_set *s) {
+    uint64_t old_cap = s->mask + 1, new_cap = old_cap * 2;
+    uint64_t *old = s->slots;
+    uint64_t *neu = (uint64_t *)calloc(new_cap, sizeof(uint64_t));
+    if (!neu) return DOR_ERR_NOMEM;
+    s->slots = neu;
+    s->mask = new_cap - 1;
+    for (uint64_t j = 0; j < old_cap; ++j) {
+        uint64_t key = old[j];
+        if (!key) continue;
+        uint64_t i = mix64(key) & s->mask;
+        while (s->slots[i]) i = (i + 1) & s->mask;
+        s->slots[i] = key;
+    }
+    free(old);
+    return 0;
+}
+
+int dor_set_contains(const dor_set *s, uint64_t key) {
+    if (key == 0) return s->has_zero;
+    uint64_t i = mix64(key) & s->mask;
+    for (;;) {
+        uint64_t cur = s->slots[i];
+        if (cur == key) return 1;
+        if (cur == 0) return 0;
+        i = (i + 1) & s->mask;
+    }
+}
+
+uint64_t dor_set_len(const dor_set *s) { return s->count; }
+
+int dor_set_insert_many(dor_set *s, const uint64_t *keys, uint64_t n) {
+    for (uint64_t i = 0; i < n; ++i)
+        if (dor_set_insert(s, keys[i]) < 0) return DOR_ERR_NOMEM;
+    return DOR_OK;
+}
+
+/* dump all keys (any order, like FxHashSet iteration); returns count */
+uint64_t dor_set_dump(const dor_set *s, uint64_t *out, uint64_t cap) {
+    uint64_t n = 0;
+    if (s->has_zero && n < cap) out[n++] = 0;
+    for (uint64_t j = 0; j <= s->mask; ++j)
+        if (s->slots[j] && n < cap) out[n++] = s->slots[j];
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7: src/filter_common.rs:129-155 `sequence_matches` / :172-198 `pair_matches`:
+ * number of DISTINCT hashes (in order of first appearance) that are in the index.
+ * ---------------------------------------------------------------------------------------- */
+uint64_t dor_count_distinct_hits(const dor_set *index, const uint64_t *hashes, uint64_t n) {
+    uint64_t hits = 0;
+    /* small local "seen" set; quadratic fallback is avoided with a scratch set */
+    dor_set *seen = dor_set_new(n < 8 ? 8 : n);
+    for (uint64_t i = 0; i < n; ++i)
+        if (dor_set_contains(index, hashes[i]) && dor_set_insert(seen, hashes[i]) == 1) hits++;
+    dor_set_free(seen);
+    return hits;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7/A8/A10: per-unit decision.  A unit is one read (src/local_filter.rs:221-252
+ * `should_keep_sequence`) or one pair (:254-285 `should_keep_pair` via
+ * src/filter_common.rs:312-348): mate 1 then mate 2, hashes concatenated, hits distinct across
+ * both mates, one decision for the pair.
+ *
+ * reads: concatenated ASCII, offsets[n_reads+1]; unit_id[n_reads] non-decreasing (NULL: one unit
+ * per read).  Outputs per unit.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dor_params {
+    uint32_t k, w;
+    uint64_t abs_threshold;
+    double rel_threshold;
+    uint64_t prefix_length;
+    int deplete;
+} dor_params;
+
+static int filter_range(const dor_set *index, const uint8_t *bases, const uint64_t *offsets,
+                        const uint32_t *unit_id, uint64_t r0, uint64_t r1, const dor_params *p,
+                        uint8_t *keep, uint32_t *hits, uint32_t *total) {
+    uint64_t cap = 0;
+    uint64_t *hbuf = NULL;
+    uint64_t r = r0;
+    while (r < r1) {
+        uint64_t u = unit_id ? unit_id[r] : r;
+        uint64_t e = r + 1;
+        if (unit_id)
+            while (e < r1 && unit_id[e] == u) e++;
+        uint64_t need = 0;
+        for (uint64_t q = r; q < e; ++q) need += offsets[q + 1] - offsets[q];
+        if (need + 1 > cap) {
+            cap = (need + 1) * 2;
+            free(hbuf);
+            hbuf = (uint64_t *)malloc(cap * sizeof(uint64_t));
+            if (!hbuf) return DOR_ERR_NOMEM;
+        }
+        uint64_t n = 0;
+        for (uint64_t q = r; q < e; ++q) {
+            uint64_t len = offsets[q + 1] - offsets[q];
+            int64_t c = dor_minimizer_hashes_and_positions(bases + offsets[q], len, p->prefix_length,
+                                                           p->k, p->w, hbuf + n, NULL, cap - n);
+            if (c < 0) {
+                free(hbuf);
+                return (int)c;
+            }
+            n += (uint64_t)c;
+        }
+        uint64_t h = dor_count_distinct_hits(index, hbuf, n);
+        keep[u] = (uint8_t)dor_meets_filtering_criteria(h, n, p->abs_threshold, p->rel_threshold,
+                                                        p->deplete);
+        if (hits) hits[u] = (uint32_t)h;
+        if (total) total[u] = (uint32_t)n;
+        r = e;
+    }
+    free(hbuf);
+    return DOR_OK;
+}
+
+int dor_filter_batch(const dor_set *index, const uint8_t *bases, const uint64_t *offsets,
+                     const uint32_t *unit_id, uint64_t n_reads, const dor_params *p, uint8_t *keep,
+                     uint32_t *hits, uint32_t *total) {
+    return filter_range(index, bases, offsets, unit_id, 0, n_reads, p, keep, hits, total);
+}
+
+/* Multithreaded driver over the same per-unit code (the "all host cores" CPU baseline leg of
+ * bench.py; stands in for the paraseq worker threads of src/local_filter.rs:696-709). */
+typedef struct mt_job {
+    const dor_set *index;
+    const uint8_t *bases;
+    const uint64_t *offsets;
+    const uint32_t *unit_id;
+    uint64_t r0, r1;
+    const dor_params *p;
+    uint8_t *keep;
+    uint32_t *hits, *total;
+    int rc;
+} mt_job;
+
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    j->rc = filter_range(j->index, j->bases, j->offsets, j->unit_id, j->r0, j->r1, j->p, j->keep,
+                         j->hits, j->total);
+    return NULL;
+}
+
+int dor_filter_batch_mt(const dor_set *index, const uint8_t *bases, const uint64_t *offsets,
+                        const uint32_t *unit_id, uint64_t n_reads, const dor_params *p,
+                        uint8_t *keep, uint32_t *hits, uint32_t *total, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n_reads) n_threads = n_reads ? (int)n_reads : 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)n_threads);
+    if (!th || !jobs) {
+        free(th);
+        free(jobs);
+        return DOR_ERR_NOMEM;
+    }
+    uint64_t start = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        uint64_t end = (t + 1 == n_threads) ? n_reads : n_reads * (uint64_t)(t + 1) / (uint64_t)n_threads;
+        /* never split a unit across threads */
+        if (unit_id)
+            while (end < n_reads && end > 0 && unit_id[end] == unit_id[end - 1]) end++;
+        if (end < start) end = start;
+        jobs[t] = (mt_job){index, bases, offsets, unit_id, start, end, p, keep, hits, total, 0};
+        start = end;
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, mt_worker, &jobs[t]);
+    int rc = DOR_OK;
+    for (int t = 0; t < n_threads; ++t) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].rc != DOR_OK) rc = jobs[t].rc;
+    }
+    free(th);
+    free(jobs);
+    return rc;
+}
+
+/* Batch seam of the server engine: src/remote_filter.rs:230-264 `unpaired_should_keep` /
+ * :266-301 `paired_should_keep` -- hashes precomputed, one unit per hash_offsets range. */
+int dor_should_keep_hashes(const dor_set *index, const uint64_t *hashes, const uint64_t *hash_offsets,
+                           uint64_t n_units, uint64_t abs_threshold, double rel_threshold,
+                           int deplete, uint8_t *keep, uint32_t *hits, uint32_t *total) {
+    for (uint64_t u = 0; u < n_units; ++u) {
+        uint64_t n = hash_offsets[u + 1] - hash_offsets[u];
+        uint64_t h = dor_count_distinct_hits(index, hashes + hash_offsets[u], n);
+        keep[u] = (uint8_t)dor_meets_filtering_criteria(h, n, abs_threshold, rel_threshold, deplete);
+        if (hits) hits[u] = (uint32_t)h;
+        if (total) total[u] = (uint32_t)n;
+    }
+    return DOR_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A9: index file, src/index.rs:17-31 (header), :80-107 (load), :130-164 (write).
+ * bincode 2.0.1 `config::standard()`: three raw u8 [format_version=2, k, w]; then count and each
+ * hash as little-endian varints: <251 -> 1 byte; 0xFB + u16; 0xFC + u32; 0xFD + u64.
+ * ---------------------------------------------------------------------------------------- */
+static int varint_read(FILE *f, uint64_t *out) {
+    int b = fgetc(f);
+    if (b == EOF) return DOR_ERR_FORMAT;
+    if (b < 251) {
+        *out = (uint64_t)b;
+        return DOR_OK;
+    }
+    int nbytes = b == 0xFB ? 2 : b == 0xFC ? 4 : b == 0xFD ? 8 : -1;
+    if (nbytes < 0) return DOR_ERR_FORMAT; /* 0xFE (u128) / 0xFF never valid for u64 */
+    uint8_t buf[8] = {0};
+    if (fread(buf, 1, (size_t)nbytes, f) != (size_t)nbytes) return DOR_ERR_FORMAT;
+    uint64_t v = 0;
+    for (int i = nbytes - 1; i >= 0; --i) v = (v << 8) | buf[i];
+    *out = v;
+    return DOR_OK;
+}
+
+static int varint_write(FILE *f, uint64_t v) {
+    uint8_t buf[9];
+    size_t n;
+    if (v < 251) {
+        buf[0] = (uint8_t)v;
+        n = 1;
+    } else if (v <= 0xFFFF) {
+        buf[0] = 0xFB;
+        n = 3;
+    } else if (v <= 0xFFFFFFFFULL) {
+        buf[0] = 0xFC;
+        n = 5;
+    } else {
+        buf[0] = 0xFD;
+        n = 9;
+    }
+    for (size_t i = 1; i < n; ++i) buf[i] = (uint8_t)(v >> (8 * (i - 1)));
+    return fwrite(buf, 1, n, f) == n ? DOR_OK : DOR_ERR_IO;
+}
+
+int dor_index_read_header(const char *path, uint8_t *k, uint8_t *w, uint64_t *count) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return DOR_ERR_IO;
+    uint8_t hdr[3];
+    int rc = DOR_OK;
+    if (fread(hdr, 1, 3, f) != 3) rc = DOR_ERR_FORMAT;
+    else if (hdr[0] != 2) rc = DOR_ERR_FORMAT; /* src/index.rs:34-43 validate() */
+    else {
+        *k = hdr[1];
+        *w = hdr[2];
+        rc = varint_read(f, count);
+    }
+    fclose(f);
+    return rc;
+}
+
+/* reads all keys into out[cap] in file order; returns count or <0 */
+int64_t dor_index_read_keys(const char *path, uint64_t *out, uint64_t cap) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return DOR_ERR_IO;
+    uint8_t hdr[3];
+    uint64_t count = 0;
+    if (fread(hdr, 1, 3, f) != 3 || hdr[0] != 2 || varint_read(f, &count) != DOR_OK) {
+        fclose(f);
+        return DOR_ERR_FORMAT;
+    }
+    if (count > cap) {
+        fclose(f);
+        return DOR_ERR_CAP;
+    }
+    for (uint64_t i = 0; i < count; ++i)
+        if (varint_read(f, &out[i]) != DOR_OK) {
+            fclose(f);
+            return DOR_ERR_FORMAT;
+        }
+    fclose(f);
+    return (int64_t)count;
+}
+
+int dor_index_write(const char *path, uint8_t k, uint8_t w, const uint64_t *keys, uint64_t n) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return DOR_ERR_IO;
+    uint8_t hdr[3] = {2, k, w};
+    int rc = fwrite(hdr, 1, 3, f) == 3 ? DOR_OK : DOR_ERR_IO;
+    if (rc == DOR_OK) rc = varint_write(f, n);
+    for (uint64_t i = 0; rc == DOR_OK && i < n; ++i) rc = varint_write(f, keys[i]);
+    if (fclose(f) != 0 && rc == DOR_OK) rc = DOR_ERR_IO;
+    return rc;
+}
+
+/* Index build from a set of sequences (src/index.rs:167-308, minus FASTX parsing): inserts the
+ * index-side hashes of one sequence into `set`. */
+int dor_index_add_sequence(dor_set *set, const uint8_t *seq, uint64_t len, uint32_t k, uint32_t w,
+                           float entropy_threshold) {
+    uint64_t l = (uint64_t)k + w - 1;
+    if (len < l) return DOR_OK;
+    uint64_t cap = len - l + 1;
+    uint64_t *h = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    if (!h) return DOR_ERR_NOMEM;
+    int64_t n = dor_index_minimizer_hashes(seq, len, k, w, entropy_threshold, h, cap);
+    if (n < 0) {
+        free(h);
+        return (int)n;
+    }
+    int rc = dor_set_insert_many(set, h, (uint64_t)n);
+    free(h);
+    return rc;
+}

@@ -1,0 +1,151 @@
+// dcn_internal.h -- shared declarations of the HIP filter pipeline (not part of the public ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/deacon_hip.h"
+
+// ----------------------------------------------------------------------------------------------------
+// error plumbing
+// ----------------------------------------------------------------------------------------------------
+void dcn_set_error(const std::string &msg);
+int dcn_fail(int code, const std::string &msg);
+
+#define DCN_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return dcn_fail(_e == hipErrorOutOfMemory ? DCN_ERR_NOMEM : DCN_ERR_HIP,               \
+                            std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+    } while (0)
+
+// ----------------------------------------------------------------------------------------------------
+// device-resident index: open-addressing set, 4-slot (32-byte) groups, linear probing over groups.
+// Slot value 0 = empty; key 0 is tracked by `has_zero`.
+// ----------------------------------------------------------------------------------------------------
+struct dcn_table_view {
+    const uint64_t *slots; // n_groups * 4
+    uint32_t group_shift;  // 32 - log2(n_groups)
+    uint32_t group_mask;   // n_groups - 1
+    uint32_t has_zero;
+};
+
+struct dcn_index {
+    int device = 0;
+    uint8_t k = 0, w = 0;
+    uint64_t n_keys = 0; // distinct
+    uint64_t n_groups = 0;
+    uint64_t *d_slots = nullptr;
+    bool has_zero = false;
+    dcn_table_view view() const {
+        dcn_table_view v;
+        v.slots = d_slots;
+        uint32_t bits = 0;
+        while ((1ull << bits) < n_groups) ++bits;
+        v.group_shift = 32 - bits;
+        v.group_mask = (uint32_t)(n_groups - 1);
+        v.has_zero = has_zero ? 1u : 0u;
+        return v;
+    }
+};
+
+// group index of a key: all 64 bits feed a 32-bit multiplicative hash, top bits select the group
+__host__ __device__ inline uint32_t dcn_group_of(uint64_t key, uint32_t group_shift, uint32_t group_mask) {
+    uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+    uint32_t x = (lo ^ ((hi << 15) | (hi >> 17))) * 0x9E3779B1u;
+    return group_shift >= 32 ? 0u : ((x >> group_shift) & group_mask);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// pipeline geometry
+// ----------------------------------------------------------------------------------------------------
+constexpr int DCN_WAVE = 64;           // one wave per workgroup in the scan kernel: 64 tiles
+constexpr int DCN_LCAP = 40;           // per-lane emitted-position list capacity between flushes
+constexpr int DCN_HCAP = 1024;         // per-wave LDS hit-hash capacity before spilling to global records
+constexpr uint32_t DCN_FRONT_PAD = 64; // u32 words of zero padding in front of the packed stream
+constexpr uint32_t DCN_TAIL_PAD = 256; // u32 words after it (lanes over-read past short tiles)
+constexpr uint32_t DCN_MAX_TILE_WINDOWS = 4096;
+
+// one tile = up to `tile_windows` consecutive windows of one read, scanned by one lane
+struct dcn_tile {
+    uint64_t scan_start; // absolute base index (in the batch stream) of the first base to scan
+    uint32_t read_pos;   // position in the read of scan_start (for reporting positions)
+    uint32_t unit;       // global unit id
+    uint32_t n_windows;  // windows whose minimizers this tile emits
+    uint32_t flags;      // bit0: has carry window (first scanned window only seeds the dedup state)
+};
+
+// status words written by the device pipeline (one per ctx, zeroed per batch)
+struct dcn_status {
+    unsigned long long rec_count; // hit records appended
+    unsigned long long set_slots; // slots needed by the distinct pass
+    uint32_t rec_overflow;        // records dropped: rec_capacity too small
+    uint32_t n_tiles;
+    unsigned long long stats[DCN_N_STATS];
+};
+
+struct dcn_scan_args {
+    const uint32_t *packed; // 2-bit stream, already offset by DCN_FRONT_PAD words
+    const uint32_t *invmask; // 1 bit per base, same padding (in 32-bit words)
+    const dcn_tile *tiles;
+    const uint32_t *n_tiles; // device-side tile count
+    const uint32_t *unit_tile_first; // n_units+1: first tile index of each unit
+    dcn_table_view table;
+    uint32_t k, w;
+    // thresholds
+    uint64_t abs_threshold;
+    double rel_threshold;
+    uint32_t deplete;
+    // outputs for units resolved inside one wave
+    uint8_t *keep;
+    uint32_t *hits, *total;
+    uint8_t *unit_state; // 1 = resolved by the scan kernel
+    // outputs for units spanning several waves
+    uint32_t *g_total;  // per unit, atomically accumulated
+    uint32_t *g_hitcnt; // per unit, number of hit records
+    uint32_t *rec_unit;
+    uint64_t *rec_hash;
+    uint64_t rec_capacity;
+    dcn_status *status;
+    // dump mode (dcn_minimizer_hashes_batch): per emitted minimizer
+    uint64_t *dump_hash;
+    uint32_t *dump_pos;
+    uint8_t *dump_valid;
+    uint32_t *dump_count; // per tile
+};
+
+// ---- kernels launched by api.hip -------------------------------------------------------------------
+int dcn_launch_pack(const uint8_t *d_ascii, uint64_t n_bases, uint32_t *d_packed, uint32_t *d_invmask,
+                    hipStream_t stream);
+int dcn_launch_scan(const dcn_scan_args &args, uint32_t max_tiles, bool dump, hipStream_t stream);
+
+int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);
+int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t n, uint8_t *out);
+
+// exclusive prefix sum of n u32 values into out[0..n] (out[n] = total); tmp holds ceil(n/1024)+1 words
+int dcn_launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *d_tmp,
+                              hipStream_t stream);
+uint32_t dcn_scan_tmp_words(uint32_t n);
+
+// required = max(abs, total==0 ? 0 : max(1, round_half_away(rel*total)))  (src/filter_common.rs:84-96)
+__host__ __device__ inline uint64_t dcn_required_hits(uint64_t abs_threshold, double rel_threshold,
+                                                      uint64_t total) {
+    uint64_t rel_required = 0;
+    if (total != 0) {
+        double r = round(rel_threshold * (double)total); // round(): half away from zero, as f64::round
+        if (!(r > 0.0)) rel_required = 0;                // Rust `as usize`: negative / NaN -> 0
+        else if (r >= 18446744073709551616.0) rel_required = ~0ull;
+        else rel_required = (uint64_t)r;
+        if (rel_required < 1) rel_required = 1;
+    }
+    return abs_threshold > rel_required ? abs_threshold : rel_required;
+}
+
+__host__ __device__ inline bool dcn_decide(uint64_t hits, uint64_t total, uint64_t abs_threshold,
+                                           double rel_threshold, uint32_t deplete) {
+    uint64_t required = dcn_required_hits(abs_threshold, rel_threshold, total);
+    return deplete ? (hits < required) : (hits >= required);
+}

@@ -1,0 +1,69 @@
+// dcn_plan.h -- argument blocks of the planning / distinct / finish kernels (plan.hip).
+#pragma once
+
+#include "dcn_internal.h"
+
+struct dcn_plan_args {
+    const uint8_t *ascii;
+    const uint64_t *offsets;
+    const uint32_t *unit_id; // may be null: unit == read
+    uint32_t n_reads, n_units;
+    uint32_t k, w;
+    uint64_t prefix_length;
+    uint32_t tile_windows;
+    uint32_t *read_windows;     // n_reads
+    uint32_t *read_tiles;       // n_reads
+    uint32_t *read_tile_first;  // n_reads + 1 (exclusive scan of read_tiles)
+    uint32_t *unit_first_read;  // n_units + 1 (only written when unit_id != null)
+    uint32_t *unit_tile_first;  // n_units + 1
+    dcn_tile *tiles;
+    dcn_status *status;
+};
+
+struct dcn_distinct_args {
+    const uint32_t *rec_unit;
+    const uint64_t *rec_hash;
+    uint64_t rec_capacity;
+    const uint32_t *g_hitcnt;
+    uint32_t *g_distinct;
+    uint32_t *g_zero;
+    uint32_t *set_off; // n_units + 1
+    uint64_t *set_slots;
+    uint64_t set_capacity;
+    uint32_t n_units;
+    dcn_status *status;
+};
+
+struct dcn_finish_args {
+    uint32_t n_units;
+    const uint32_t *unit_first_read; // null: unit == read
+    const uint64_t *offsets;         // null: no counters (hash seam)
+    const uint8_t *unit_state;
+    const uint32_t *g_total, *g_distinct;
+    uint64_t abs_threshold;
+    double rel_threshold;
+    uint32_t deplete;
+    uint8_t *keep;
+    uint32_t *hits, *total;
+    unsigned long long *status_stats;
+    const dcn_status *status;
+};
+
+struct dcn_probe_hashes_args {
+    dcn_table_view table;
+    const uint64_t *hashes;
+    const uint64_t *hash_offsets;
+    uint64_t n_hashes;
+    uint32_t n_units;
+    uint32_t *g_total, *g_hitcnt;
+    uint32_t *rec_unit;
+    uint64_t *rec_hash;
+    uint64_t rec_capacity;
+    dcn_status *status;
+};
+
+int dcn_launch_plan_reads(const dcn_plan_args &a, hipStream_t stream);
+int dcn_launch_plan_tiles(const dcn_plan_args &a, hipStream_t stream);
+int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *d_scan_tmp, hipStream_t stream);
+int dcn_launch_finish(const dcn_finish_args &a, hipStream_t stream);
+int dcn_launch_probe_hashes(const dcn_probe_hashes_args &a, hipStream_t stream);

@@ -1,0 +1,91 @@
+// pack.hip -- K1: ASCII -> 2-bit stream + invalid-base bitmask, for the whole batch buffer at once.
+//
+// Replaces packed_seq::PackedSeqVec::from_ascii and the invalid-mask loop of
+// get_minimizer_hashes_and_positions (src/filter_common.rs:238-258):
+//   code = (c >> 1) & 3 for EVERY byte (A=0 C=1 T=2 G=3; non-ACGT mapped the same lossy way);
+//   mask bit = 1 iff the byte is not one of ACGTacgt.
+// Reads are concatenated with no separators, so the batch is packed as one dense stream: base i of the
+// batch is bits [2(i%16), 2(i%16)+2) of packed[i/16] and bit i%32 of invmask[i/32]; no kernel here
+// needs to know where reads begin.  HBM-bound: 1 B/bp read, 0.375 B/bp written.
+#include "dcn_internal.h"
+
+namespace {
+
+__device__ inline uint32_t pack4(uint32_t x) {
+    // 4 ASCII bytes -> 8 bits of 2-bit codes (byte 0 in bits 0..1)
+    uint32_t y = (x >> 1) & 0x03030303u;
+    return (y * ((1u << 24) | (1u << 18) | (1u << 12) | (1u << 6))) >> 24;
+}
+
+__device__ inline uint32_t invalid4(uint32_t x) {
+    // 4 ASCII bytes -> 4 bits, bit j = byte j is not in ACGTacgt
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t c = ((x >> (8 * j)) & 0xFFu) | 0x20u;
+        bool ok = (c == 'a') | (c == 'c') | (c == 'g') | (c == 't');
+        m |= (ok ? 0u : 1u) << j;
+    }
+    return m;
+}
+
+// each thread packs 32 bases: two packed words and one mask word
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, uint64_t n_bases,
+                                                   uint32_t *__restrict__ packed,
+                                                   uint32_t *__restrict__ invmask, uint64_t n_chunks) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_chunks; t += stride) {
+        uint64_t base = t * 32;
+        uint32_t w[8];
+        if (ALIGNED && base + 32 <= n_bases) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(ascii + base);
+            uint4 a = p[0], b = p[1];
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+            w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint64_t i = base + 4 * q + j;
+                    // bases past the end are packed as 'A' and flagged valid; no window ever reaches them
+                    uint32_t c = i < n_bases ? ascii[i] : (uint32_t)'A';
+                    v |= c << (8 * j);
+                }
+                w[q] = v;
+            }
+        }
+        uint32_t p0 = 0, p1 = 0, m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p0 |= pack4(w[q]) << (8 * q);
+            p1 |= pack4(w[q + 4]) << (8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m |= invalid4(w[q]) << (4 * q);
+        packed[2 * t] = p0;
+        packed[2 * t + 1] = p1;
+        invmask[t] = m;
+    }
+}
+
+} // namespace
+
+int dcn_launch_pack(const uint8_t *d_ascii, uint64_t n_bases, uint32_t *d_packed, uint32_t *d_invmask,
+                    hipStream_t stream) {
+    uint64_t n_chunks = (n_bases + 31) / 32;
+    if (n_chunks == 0) return DCN_OK;
+    uint32_t blocks = (uint32_t)((n_chunks + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    bool aligned = (reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0;
+    if (aligned)
+        hipLaunchKernelGGL(pack_kernel<true>, dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed,
+                           d_invmask, n_chunks);
+    else
+        hipLaunchKernelGGL(pack_kernel<false>, dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed,
+                           d_invmask, n_chunks);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}

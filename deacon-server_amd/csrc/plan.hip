@@ -1,0 +1,236 @@
+// plan.hip -- the small kernels around the scan: tile planning (A1 of SURVEY.md section 8a), the exact
+// distinct-hit pass for units that span several waves, the per-unit decision and the six counters.
+#include "dcn_internal.h"
+#include "dcn_plan.h"
+#include "dcn_probe.h"
+
+namespace {
+
+// ---- A1: effective sequence -> number of windows (src/filter_common.rs:217-229) -------------------------
+__device__ inline uint32_t effective_windows(const uint8_t *ascii, uint64_t off, uint64_t len, uint64_t prefix,
+                                             uint32_t k, uint32_t l) {
+    if (len < k) return 0;                      // :217 -- tested on the full read, before the prefix cut
+    uint64_t n = (prefix > 0 && len > prefix) ? prefix : len; // :222-226
+    if (n > 0 && ascii[off + n - 1] == '\n') n -= 1;          // :229
+    return n >= l ? (uint32_t)(n - l + 1) : 0;
+}
+
+__global__ __launch_bounds__(256) void plan_reads_kernel(dcn_plan_args a) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    uint64_t off = a.offsets[r], len = a.offsets[r + 1] - off;
+    uint32_t nwin = effective_windows(a.ascii, off, len, a.prefix_length, a.k, a.k + a.w - 1);
+    a.read_windows[r] = nwin;
+    a.read_tiles[r] = (nwin + a.tile_windows - 1) / a.tile_windows;
+    if (a.unit_id) {
+        uint32_t u = a.unit_id[r];
+        if (r == 0 || a.unit_id[r - 1] != u) a.unit_first_read[u] = r;
+        if (r == a.n_reads - 1) a.unit_first_read[a.n_units] = a.n_reads;
+    }
+}
+
+__global__ __launch_bounds__(256) void plan_tiles_kernel(dcn_plan_args a) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_reads) return;
+    uint32_t first = a.read_tile_first[r], nt = a.read_tile_first[r + 1] - first;
+    uint32_t u = a.unit_id ? a.unit_id[r] : r;
+    bool unit_head = a.unit_id ? (r == 0 || a.unit_id[r - 1] != u) : true;
+    if (unit_head) a.unit_tile_first[u] = first;
+    if (r == a.n_reads - 1) {
+        uint32_t total = a.read_tile_first[a.n_reads];
+        a.unit_tile_first[a.n_units] = total;
+        a.status->n_tiles = total;
+    }
+    uint32_t nwin = a.read_windows[r];
+    uint64_t off = a.offsets[r];
+    for (uint32_t j = 0; j < nt; ++j) {
+        uint32_t wstart = j * a.tile_windows;
+        uint32_t carry = j > 0 ? 1u : 0u;
+        dcn_tile t;
+        t.scan_start = off + wstart - carry;
+        t.read_pos = wstart - carry;
+        t.unit = u;
+        t.n_windows = min(a.tile_windows, nwin - wstart);
+        t.flags = carry;
+        a.tiles[first + j] = t;
+    }
+}
+
+// ---- exact distinct-hit count from (unit, hash) records ------------------------------------------------------
+__global__ __launch_bounds__(256) void distinct_cap_kernel(const uint32_t *g_hitcnt, uint32_t n_units, uint32_t *caps) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_units) return;
+    uint32_t hc = g_hitcnt[u];
+    uint32_t cap = 0;
+    if (hc) {
+        cap = 2;
+        while (cap < 2u * hc && cap < (1u << 31)) cap <<= 1;
+    }
+    caps[u] = cap;
+}
+
+__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, const uint32_t *set_off,
+                                                            uint32_t n_units, uint64_t capacity) {
+    uint64_t total = set_off[n_units];
+    if (total > capacity) total = capacity;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) set_slots[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void distinct_insert_kernel(dcn_distinct_args a) {
+    unsigned long long n = a.status->rec_count;
+    if (n > a.rec_capacity) n = a.rec_capacity;
+    uint64_t total_slots = a.set_off[a.n_units];
+    if (total_slots > a.set_capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.status->rec_overflow = 1;
+        return;
+    }
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t u = a.rec_unit[i];
+        uint64_t h = a.rec_hash[i];
+        if (h == 0) { // 0 marks an empty slot: a zero hash is tracked by a per-unit flag
+            if (atomicExch(&a.g_zero[u], 1u) == 0u) atomicAdd(&a.g_distinct[u], 1u);
+            continue;
+        }
+        uint32_t cap = a.set_off[u + 1] - a.set_off[u];
+        unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
+        uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+        uint32_t slot = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x85EBCA6Bu) & (cap - 1);
+        for (;;) {
+            unsigned long long old = atomicCAS(&region[slot], 0ull, (unsigned long long)h);
+            if (old == 0) {
+                atomicAdd(&a.g_distinct[u], 1u);
+                break;
+            }
+            if (old == h) break;
+            slot = (slot + 1) & (cap - 1);
+        }
+    }
+}
+
+// ---- A7/A10: decision for units not resolved by the scan kernel + the six counters ----------------------------
+__global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long st[DCN_N_STATS] = {0, 0, 0, 0, 0, 0};
+    if (u < a.n_units) {
+        uint32_t r0 = a.unit_first_read ? a.unit_first_read[u] : u;
+        uint32_t r1 = a.unit_first_read ? a.unit_first_read[u + 1] : u + 1;
+        bool keep;
+        if (a.unit_state[u]) {
+            keep = a.keep[u] != 0;
+        } else {
+            uint32_t tot = a.g_total[u], hc = a.g_distinct[u];
+            keep = dcn_decide(hc, tot, a.abs_threshold, a.rel_threshold, a.deplete);
+            a.keep[u] = keep ? 1 : 0;
+            if (a.hits) a.hits[u] = hc;
+            if (a.total) a.total[u] = tot;
+        }
+        if (a.offsets) {
+            // ProcessingStats, src/local_filter.rs:346-371 (single) / :417-445 (pair)
+            unsigned long long nseq = r1 - r0, bp = a.offsets[r1] - a.offsets[r0];
+            st[DCN_STAT_TOTAL_SEQS] = nseq;
+            st[DCN_STAT_TOTAL_BP] = bp;
+            if (keep) {
+                st[DCN_STAT_OUTPUT_BP] = bp;
+                st[DCN_STAT_OUTPUT_SEQ_COUNTER] = nseq;
+            } else {
+                st[DCN_STAT_FILTERED_SEQS] = nseq;
+                st[DCN_STAT_FILTERED_BP] = bp;
+            }
+        }
+    }
+    if (!a.offsets || a.status->rec_overflow) return; // an overflowed attempt is re-run: do not count it
+    __shared__ unsigned long long red[DCN_N_STATS][4];
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < DCN_N_STATS; ++c) {
+        unsigned long long v = st[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[c][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < DCN_N_STATS) {
+        unsigned long long v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (v) atomicAdd(&a.status_stats[threadIdx.x], v);
+    }
+}
+
+// ---- server seam: probe precomputed hashes (src/remote_filter.rs:230-301) ------------------------------------
+__global__ __launch_bounds__(256) void probe_hashes_kernel(dcn_probe_hashes_args a) {
+    uint64_t n = a.n_hashes;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t h = a.hashes[i];
+        if (!dcn_table_contains_dev(a.table, h)) continue;
+        // unit = largest u with hash_offsets[u] <= i
+        uint32_t lo = 0, hi = a.n_units - 1;
+        while (lo < hi) {
+            uint32_t mid = lo + (hi - lo + 1) / 2;
+            if (a.hash_offsets[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        unsigned long long r = atomicAdd(&a.status->rec_count, 1ull);
+        if (r < a.rec_capacity) {
+            a.rec_unit[r] = lo;
+            a.rec_hash[r] = h;
+            atomicAdd(&a.g_hitcnt[lo], 1u);
+        } else {
+            a.status->rec_overflow = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void hash_totals_kernel(const uint64_t *hash_offsets, uint32_t n_units,
+                                                         uint32_t *g_total) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n_units) g_total[u] = (uint32_t)(hash_offsets[u + 1] - hash_offsets[u]);
+}
+
+inline uint32_t blocks_for(uint64_t n, uint32_t cap = 256 * 16) {
+    uint64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (uint32_t)(b > cap ? cap : b);
+}
+
+} // namespace
+
+int dcn_launch_plan_reads(const dcn_plan_args &a, hipStream_t stream) {
+    hipLaunchKernelGGL(plan_reads_kernel, dim3((a.n_reads + 255) / 256), dim3(256), 0, stream, a);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}
+
+int dcn_launch_plan_tiles(const dcn_plan_args &a, hipStream_t stream) {
+    hipLaunchKernelGGL(plan_tiles_kernel, dim3((a.n_reads + 255) / 256), dim3(256), 0, stream, a);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}
+
+int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *d_scan_tmp, hipStream_t stream) {
+    hipLaunchKernelGGL(distinct_cap_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a.g_hitcnt,
+                       a.n_units, d_caps);
+    int rc = dcn_launch_exclusive_scan(d_caps, a.set_off, a.n_units, d_scan_tmp, stream);
+    if (rc != DCN_OK) return rc;
+    hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_off, a.n_units,
+                       a.set_capacity);
+    hipLaunchKernelGGL(distinct_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}
+
+int dcn_launch_finish(const dcn_finish_args &a, hipStream_t stream) {
+    hipLaunchKernelGGL(finish_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}
+
+int dcn_launch_probe_hashes(const dcn_probe_hashes_args &a, hipStream_t stream) {
+    hipLaunchKernelGGL(hash_totals_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a.hash_offsets,
+                       a.n_units, a.g_total);
+    if (a.n_hashes)
+        hipLaunchKernelGGL(probe_hashes_kernel, dim3(blocks_for(a.n_hashes)), dim3(256), 0, stream, a);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}

@@ -1,0 +1,160 @@
+/*
+ * deacon_hip.h -- C ABI of the MI355X-native read-filtering core for Deacon.
+ *
+ * This is the drop-in boundary for ONE path of the reference (crate deacon 0.10.0): the per-read
+ * "pack -> canonical minimizer scan -> k-mer hash -> index probe -> distinct-hit count -> threshold"
+ * loop that `deacon filter` runs on CPU worker threads.  The reference has no FFI of its own; each
+ * entry point below names the Rust item (file:line under the reference's src/) it replaces.  A Rust
+ * maintainer binds them with a plain `extern "C"` block.
+ *
+ * Conventions
+ *   - every function returns DCN_OK (0) or a negative DCN_ERR_* code and never aborts;
+ *     dcn_last_error() returns a thread-local message for the last failure on this thread;
+ *   - plain pointers and sizes only; "host" pointers are ordinary process memory, "device" pointers are
+ *     HIP device allocations on the context's GPU;
+ *   - a dcn_index is immutable after creation and may be shared by any number of contexts/threads
+ *     (the reference shares its set through an Arc: src/local_filter.rs:156,631);
+ *   - a dcn_ctx owns one HIP stream pair plus staging/scratch buffers and is NOT thread-safe: use one
+ *     per host thread (the reference clones one FilterProcessor per worker: src/local_filter.rs:153).
+ */
+#ifndef DEACON_HIP_H
+#define DEACON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCN_OK 0
+#define DCN_ERR_ARG (-1)      /* invalid argument (NULL, k/w out of range, k+w-1 even, ...) */
+#define DCN_ERR_HIP (-2)      /* a HIP runtime call failed (message has the HIP error string) */
+#define DCN_ERR_NOMEM (-3)    /* host or device allocation failed */
+#define DCN_ERR_IO (-4)       /* index file could not be opened / read */
+#define DCN_ERR_FORMAT (-5)   /* index file is not a format-version-2 deacon index */
+#define DCN_ERR_CAPACITY (-6) /* batch larger than the context was created for, or output too small */
+#define DCN_ERR_INTERNAL (-7)
+
+typedef struct dcn_index dcn_index; /* device-resident minimizer set: replaces Arc<FxHashSet<u64>> */
+typedef struct dcn_ctx dcn_ctx;     /* per-thread pipeline context */
+
+/* Filter-time parameters: the fields of FilterProcessor that the decision depends on
+ * (src/local_filter.rs:159-162; CLI defaults -a 2 -r 0.01 -p 0, src/main.rs:43-60).
+ * k and w are NOT here: like the reference they come from the index header
+ * (src/local_filter.rs:633-634). */
+typedef struct dcn_params {
+    uint64_t abs_threshold; /* -a: minimum absolute number of distinct minimizer hits */
+    double rel_threshold;   /* -r: minimum hits relative to the unit's minimizer count */
+    uint64_t prefix_length; /* -p: 0 = whole read, else only the first prefix_length bases */
+    uint32_t deplete;       /* -d: 0 = keep matching units, 1 = keep non-matching units */
+    uint32_t reserved;      /* must be 0 */
+} dcn_params;
+
+/* The six ProcessingStats counters of src/local_filter.rs:179-187, in that order. */
+enum {
+    DCN_STAT_TOTAL_SEQS = 0,
+    DCN_STAT_FILTERED_SEQS = 1,
+    DCN_STAT_TOTAL_BP = 2,
+    DCN_STAT_OUTPUT_BP = 3,
+    DCN_STAT_FILTERED_BP = 4,
+    DCN_STAT_OUTPUT_SEQ_COUNTER = 5,
+    DCN_N_STATS = 6
+};
+
+/* ---- library ------------------------------------------------------------------------------------ */
+const char *dcn_version(void);
+const char *dcn_last_error(void);
+int dcn_device_count(int *count);
+
+/* ---- index: replaces index::load_minimizer_hashes (src/index.rs:80-107) ----------------------------- */
+
+/* Build the device set from `n` host u64 minimizer hashes (duplicates allowed; they are merged, as by
+ * FxHashSet::insert at src/index.rs:104).  k, w as in IndexHeader (src/index.rs:17-31): 1<=k<=56
+ * (the filter path asserts k<=56 at src/filter_common.rs:269), w>=1, k+w-1 odd (src/index.rs:186-194). */
+int dcn_index_from_keys(const uint64_t *keys, uint64_t n, uint8_t k, uint8_t w, int device, dcn_index **out);
+
+/* Load a deacon index file (bincode 2 "standard" varint layout written by write_minimizers,
+ * src/index.rs:130-164; header validation as IndexHeader::validate, src/index.rs:34-43). */
+int dcn_index_from_file(const char *path, int device, dcn_index **out);
+
+/* Header fields and the number of DISTINCT keys (what `deacon index info` prints, src/index.rs:539-560). */
+int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n_keys);
+
+/* Set membership for `n` host keys -> out[i] in {0,1}: FxHashSet::contains (src/filter_common.rs:144). */
+int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n, uint8_t *out);
+
+void dcn_index_destroy(dcn_index *index);
+
+/* ---- context -------------------------------------------------------------------------------------- */
+
+/* max_batch_bases / max_batch_reads bound one call of dcn_filter_batch*; buffers are sized once here. */
+int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, uint32_t max_batch_reads, dcn_ctx **out);
+void dcn_ctx_destroy(dcn_ctx *ctx);
+
+/* ---- the hot path -------------------------------------------------------------------------------- */
+
+/* Filter one batch of reads held in host memory.  Replaces, for every unit of the batch,
+ * FilterProcessor::should_keep_sequence (src/local_filter.rs:221-252) or ::should_keep_pair (:254-285),
+ * i.e. get_minimizer_hashes_and_positions (src/filter_common.rs:211-310) + sequence_matches /
+ * pair_matches (:129-198) + meets_filtering_criteria (:99-112).
+ *
+ *   bases    concatenated ASCII sequences (record.seq() bytes, no separators), offsets[n_reads] bytes
+ *   offsets  n_reads+1 byte offsets into `bases`, offsets[0] == 0, non-decreasing
+ *   unit_id  NULL: every read is its own unit.  Otherwise n_reads entries, unit_id[0]==0, each
+ *            entry equal to its predecessor or predecessor+1: consecutive reads with equal id form
+ *            one unit (a pair: mate 1 then mate 2 -- src/filter_common.rs:312-348)
+ *   keep     out, one byte per unit: 1 = write the unit's records to the output, 0 = drop
+ *   hits     out (may be NULL), distinct minimizer hits per unit
+ *   total    out (may be NULL), minimizer count per unit (duplicates included) -- the
+ *            (bool, usize, usize) of should_keep_*
+ * Blocking; internally pinned staging + hipMemcpyAsync on a side stream overlapped with the kernels. */
+int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
+                     uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
+                     uint32_t *total);
+
+/* Same computation on inputs already resident in device memory (all pointers are DEVICE pointers on the
+ * context's GPU; d_unit_id / d_hits / d_total may be NULL).  n_bases = offsets[n_reads], n_units = number
+ * of units (n_reads when d_unit_id is NULL).  Enqueues on the context's stream and returns without
+ * waiting; call dcn_ctx_synchronize() before reading the outputs. */
+int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
+                            const uint32_t *d_unit_id, uint32_t n_reads, uint64_t n_bases, uint32_t n_units,
+                            const dcn_params *params, uint8_t *d_keep, uint32_t *d_hits, uint32_t *d_total);
+
+/* Wait for everything enqueued on the context; reports deferred errors of the device pipeline
+ * (e.g. DCN_ERR_CAPACITY when a scratch buffer overflowed; the batch must then be re-submitted after
+ * dcn_ctx_reserve_records()). */
+int dcn_ctx_synchronize(dcn_ctx *ctx);
+
+/* Grow the scratch that holds (unit, hash) hit records of units spanning several tiles (long reads). */
+int dcn_ctx_reserve_records(dcn_ctx *ctx, uint64_t n_records);
+
+/* Raw HIP stream (hipStream_t) the context enqueues on, so a caller can time or order against it. */
+void *dcn_ctx_stream(dcn_ctx *ctx);
+
+/* Minimizer hashes and positions of every read of a host batch: the (Vec<u64>, Vec<u32>) of
+ * get_minimizer_hashes_and_positions (src/filter_common.rs:211-310), concatenated read by read.
+ *   out_offsets  n_reads+1 entries: read r owns [out_offsets[r], out_offsets[r+1]) of the two arrays
+ *   capacity     entries available in out_hashes / out_positions; on DCN_ERR_CAPACITY
+ *                out_offsets[n_reads] holds the required size */
+int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                               uint64_t prefix_length, uint64_t *out_offsets, uint64_t *out_hashes,
+                               uint32_t *out_positions, uint64_t capacity);
+
+/* Batch seam of the server engine: unpaired_should_keep / paired_should_keep
+ * (src/remote_filter.rs:230-301) -- minimizer hashes precomputed by the client, unit u owns
+ * hashes[hash_offsets[u] .. hash_offsets[u+1]) (for a pair: both mates' hashes concatenated).
+ * Host pointers; hits/total may be NULL.  prefix_length of params is ignored here. */
+int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, const uint64_t *hash_offsets, uint32_t n_units,
+                           const dcn_params *params, uint8_t *keep, uint32_t *hits, uint32_t *total);
+
+/* ---- counters: ProcessingStats (src/local_filter.rs:179-187, merged at :388-396) -------------------------- */
+
+/* Counters accumulated on the device over every dcn_filter_batch* call since the last reset. */
+int dcn_ctx_stats(dcn_ctx *ctx, uint64_t counters[DCN_N_STATS]);
+int dcn_ctx_reset_stats(dcn_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEACON_HIP_H */

@@ -1,0 +1,80 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_count():
+    try:
+        import deacon_server_amd as d
+        import ctypes
+        n = ctypes.c_int()
+        if d._native.lib().dcn_device_count(ctypes.byref(n)) != 0:
+            return 0
+        return n.value
+    except Exception:
+        return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    # -m gpu on a box without a GPU must fail loudly, not skip: only unmarked runs skip gpu tests
+    if config.getoption("-m") and "gpu" in config.getoption("-m") and "not gpu" not in config.getoption("-m"):
+        return
+    if _gpu_count() == 0:
+        skip = pytest.mark.skip(reason="no GPU in this container (run with -m gpu on the GPU box)")
+        for item in items:
+            if "gpu" in item.keywords:
+                item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def dcn():
+    import deacon_server_amd as d
+    return d
+
+
+def random_reads(rng, n, min_len, max_len, p_n=0.0, p_lower=0.0, alphabet=b"ACGT"):
+    reads = []
+    alpha = np.frombuffer(alphabet, dtype=np.uint8)
+    for _ in range(n):
+        ln = int(rng.integers(min_len, max_len + 1))
+        s = alpha[rng.integers(0, len(alpha), ln)].copy()
+        if p_n > 0 and ln:
+            m = rng.random(ln) < p_n
+            s[m] = ord("N")
+        if p_lower > 0 and ln:
+            m = rng.random(ln) < p_lower
+            s[m] |= 0x20
+        reads.append(s.tobytes())
+    return reads
+
+
+def mutate(rng, seq, rate):
+    s = np.frombuffer(seq, dtype=np.uint8).copy()
+    m = rng.random(len(s)) < rate
+    s[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(m.sum()))]
+    return s.tobytes()
+
+
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def revcomp(seq):
+    return bytes(seq).translate(_COMP)[::-1]

@@ -1,0 +1,101 @@
+"""CPU checks of the drop-in boundary: the shared library builds, loads, exports every symbol the header
+declares, and fails loudly (error code + message, no abort, no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+
+def test_library_present_and_exports_every_declared_symbol(dcn):
+    N = dcn._native
+    assert os.path.exists(N.LIB_PATH), "build with __graft_entry__.build()"
+    L = C.CDLL(N.LIB_PATH)
+    declared = N.declared_symbols()
+    assert len(declared) >= 19
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/deacon_hip.h but not exported"
+    # and the binding table covers exactly the declared surface
+    assert sorted(N._SIGNATURES) == declared
+
+
+def test_exports_are_c_abi(dcn):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", dcn._native.LIB_PATH], text=True)
+    syms = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    for name in dcn._native.declared_symbols():
+        assert name in syms  # unmangled => extern "C"
+
+
+def test_params_layout_matches_header(dcn):
+    P = dcn._native.Params
+    assert C.sizeof(P) == 32
+    assert (P.abs_threshold.offset, P.rel_threshold.offset, P.prefix_length.offset,
+            P.deplete.offset, P.reserved.offset) == (0, 8, 16, 24, 28)
+
+
+def test_header_compiles_as_plain_c(tmp_path, dcn):
+    src = tmp_path / "t.c"
+    src.write_text('#include "deacon_hip.h"\nint main(void){ dcn_params p; (void)p; return DCN_N_STATS == 6 ? 0 : 1; }\n')
+    inc = os.path.dirname(dcn._native.HEADER_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", inc, str(src), "-o",
+                           str(tmp_path / "t")])
+    assert subprocess.call([str(tmp_path / "t")]) == 0
+
+
+def test_version_and_argument_errors(dcn):
+    L = dcn._native.lib()
+    assert b"deacon-hip" in L.dcn_version()
+    h = C.c_void_p()
+    keys = np.arange(10, dtype=np.uint64)
+    kp = keys.ctypes.data_as(C.c_void_p)
+    assert L.dcn_index_from_keys(kp, 10, 31, 15, 0, None) == dcn._native.DCN_ERR_ARG
+    assert L.dcn_index_from_keys(kp, 10, 31, 16, 0, C.byref(h)) == dcn._native.DCN_ERR_ARG  # k+w-1 even
+    assert b"odd" in L.dcn_last_error()
+    assert L.dcn_index_from_keys(kp, 10, 57, 15, 0, C.byref(h)) == dcn._native.DCN_ERR_ARG  # k > 56
+    assert L.dcn_index_from_keys(None, 10, 31, 15, 0, C.byref(h)) == dcn._native.DCN_ERR_ARG
+    assert L.dcn_ctx_create(None, 1 << 20, 1 << 10, C.byref(h)) == dcn._native.DCN_ERR_ARG
+    assert L.dcn_ctx_synchronize(None) == dcn._native.DCN_ERR_ARG
+    assert L.dcn_index_header(None, None, None, None) == dcn._native.DCN_ERR_ARG
+    L.dcn_index_destroy(None)  # no-ops, must not crash
+    L.dcn_ctx_destroy(None)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(dcn):
+    L = dcn._native.lib()
+    n = C.c_int(-1)
+    rc = L.dcn_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    keys = np.arange(1, 100, dtype=np.uint64)
+    with pytest.raises(dcn.DeaconHipError) as e:
+        dcn.Index.from_keys(keys, 31, 15)
+    assert e.value.code in (dcn._native.DCN_ERR_HIP, dcn._native.DCN_ERR_ARG)
+
+
+def test_index_file_errors(dcn, tmp_path):
+    L = dcn._native.lib()
+    h = C.c_void_p()
+    assert L.dcn_index_from_file(os.fsencode(tmp_path / "missing.idx"), 0, C.byref(h)) == dcn._native.DCN_ERR_IO
+    bad = tmp_path / "bad.idx"
+    bad.write_bytes(bytes([1, 31, 15, 0]))
+    assert L.dcn_index_from_file(os.fsencode(bad), 0, C.byref(h)) == dcn._native.DCN_ERR_FORMAT
+    assert b"format version" in L.dcn_last_error()
+    trunc = tmp_path / "trunc.idx"
+    trunc.write_bytes(bytes([2, 31, 15, 5, 0xFD, 1, 2]))
+    assert L.dcn_index_from_file(os.fsencode(trunc), 0, C.byref(h)) == dcn._native.DCN_ERR_FORMAT
+
+
+def test_product_does_not_reference_the_oracle(dcn):
+    """The oracle is test infrastructure: nothing in the product package may import, link or mention it."""
+    pkg = os.path.dirname(dcn._native.LIB_PATH)
+    pkg = os.path.dirname(pkg)
+    for root, _, files in os.walk(pkg):
+        if os.path.basename(root) in ("build", "lib", "__pycache__"):
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "liboracle" not in text and "deacon_oracle" not in text and "from oracle" not in text, f
+    out = subprocess.check_output(["ldd", dcn._native.LIB_PATH], text=True)
+    assert "oracle" not in out

@@ -1,0 +1,436 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs, bit-exact.
+
+Everything here runs through lib/libdeacon_hip.so; the oracle is only the checker."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, mutate, random_reads, revcomp
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------------
+def make_index_pair(oracle, dcn, seqs, k=31, w=15, extra_keys=()):
+    """Build the same index for both sides: oracle set + device table from the oracle's key list."""
+    oidx = oracle.Index.build(seqs, k=k, w=w)
+    keys = oidx.keys()
+    if len(extra_keys):
+        keys = np.concatenate([keys, np.asarray(extra_keys, dtype=np.uint64)])
+        oidx = oracle.Index(keys, k, w)
+    gidx = dcn.Index.from_keys(keys, k, w)
+    assert gidx.n_keys == len(oidx)
+    return oidx, gidx
+
+
+def check_batch(oracle, proc, oidx, reads, unit_id=None, **kw):
+    b, o = oracle.concat_reads(reads)
+    want = oracle.filter_batch(oidx, b, o, unit_id, abs_threshold=proc.abs_threshold,
+                               rel_threshold=proc.rel_threshold, prefix_length=proc.prefix_length,
+                               deplete=proc.deplete, threads=4)
+    got = proc.filter_batch(b, o, unit_id)
+    assert got[2].tolist() == want[2].tolist(), "total minimizers differ"
+    assert got[1].tolist() == want[1].tolist(), "distinct hit counts differ"
+    assert got[0].tolist() == want[0].tolist(), "keep decisions differ"
+    return got
+
+
+@pytest.fixture(scope="module")
+def genome():
+    return random_reads(np.random.default_rng(1), 1, 200_000, 200_000)[0]
+
+
+@pytest.fixture(scope="module")
+def index_pair(oracle, dcn, genome):
+    return make_index_pair(oracle, dcn, [genome])
+
+
+def sample_reads(rng, genome, n, min_len, max_len, host_frac=0.5, sub=0.005, p_n=0.001):
+    reads = []
+    for _ in range(n):
+        ln = int(rng.integers(min_len, max_len + 1))
+        if rng.random() < host_frac and ln < len(genome):
+            s = int(rng.integers(0, len(genome) - ln))
+            r = mutate(rng, genome[s:s + ln], sub)
+            if rng.random() < 0.5:
+                r = revcomp(r)
+        else:
+            r = random_reads(rng, 1, ln, ln)[0]
+        if p_n > 0 and ln:
+            a = np.frombuffer(r, dtype=np.uint8).copy()
+            a[rng.random(ln) < p_n] = ord("N")
+            r = a.tobytes()
+        reads.append(r)
+    return reads
+
+
+# ------------------------------------------------------------------------------------------------------
+# K4: the device set
+# ------------------------------------------------------------------------------------------------------
+def test_table_membership(dcn):
+    rng = np.random.default_rng(2)
+    keys = rng.integers(0, 2**63, 300_000, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, 300_000).astype(np.uint64)
+    keys = np.concatenate([keys, keys[:1000], np.array([0, 1, 2**64 - 1], np.uint64)])  # duplicates, zero, max
+    idx = dcn.Index.from_keys(keys, 31, 15)
+    assert idx.header() == (31, 15, len(set(keys.tolist())))
+    probe = np.concatenate([keys[::7], rng.integers(0, 2**63, 100_000, dtype=np.uint64), np.array([0, 3], np.uint64)])
+    want = np.isin(probe, keys)
+    assert idx.contains(probe).tolist() == want.tolist()
+    empty = dcn.Index.from_keys(np.zeros(0, np.uint64), 31, 15)
+    assert empty.n_keys == 0 and not empty.contains(probe[:100]).any()
+    only_zero = dcn.Index.from_keys(np.zeros(3, np.uint64), 31, 15)
+    assert only_zero.n_keys == 1 and only_zero.contains(np.array([0, 1], np.uint64)).tolist() == [True, False]
+
+
+def test_table_adversarial_keys(dcn):
+    # keys that collide in the low / high bits must still be exact
+    a = (np.arange(1, 50_001, dtype=np.uint64) << np.uint64(40))
+    b = np.arange(1, 50_001, dtype=np.uint64)
+    keys = np.concatenate([a, b])
+    idx = dcn.Index.from_keys(keys, 31, 15)
+    assert idx.n_keys == 100_000
+    probe = np.concatenate([a[:1000], b[:1000], a[:1000] + np.uint64(1), b[:1000] + np.uint64(50_000)])
+    assert idx.contains(probe).tolist() == [True] * 2000 + [False] * 2000
+
+
+def test_index_from_file(oracle, dcn, tmp_path, genome):
+    oidx = oracle.Index.build([genome[:50_000]], k=31, w=15)
+    path = tmp_path / "g.idx"
+    oidx.write(path)
+    gidx = dcn.Index.from_file(str(path))
+    assert gidx.header() == (31, 15, len(oidx))
+    keys = oidx.keys()
+    assert gidx.contains(keys).all()
+    assert not gidx.contains(keys ^ np.uint64(1)).all()
+
+
+# ------------------------------------------------------------------------------------------------------
+# K1-K3: minimizer positions and hashes
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,w", [(31, 15), (15, 11), (41, 15), (5, 5), (31, 1), (21, 9), (32, 15), (33, 15), (56, 2)])
+def test_minimizer_hashes_and_positions_parity(oracle, dcn, k, w):
+    rng = np.random.default_rng(k * 1000 + w)
+    reads = random_reads(rng, 300, 0, 700, p_n=0.003, p_lower=0.05)
+    reads += [b"", b"A", b"ACGT" * 40, b"A" * 150, b"AT" * 80, b"GGGCCC" * 30, b"N" * 100,
+              b"ACGTNACGT" * 20, random_reads(rng, 1, 149, 149)[0] + b"\n", b"acgtacgtggccaattgcat" * 8]
+    reads += random_reads(rng, 5, 3000, 9000, p_n=0.001)  # multi-tile
+    idx = dcn.Index.from_keys(np.arange(1, 10, dtype=np.uint64), k, w)
+    proc = dcn.FilterProcessor(idx, max_batch_bases=1 << 21, max_batch_reads=4096)
+    b, o = oracle.concat_reads(reads)
+    off, h, p = proc.minimizer_hashes_batch(b, o)
+    for r, s in enumerate(reads):
+        wh, wp = oracle.minimizer_hashes_and_positions(s, k, w)
+        lo, hi = int(off[r]), int(off[r + 1])
+        assert p[lo:hi].tolist() == wp.tolist(), (r, len(s))
+        assert h[lo:hi].tolist() == wh.tolist(), (r, len(s))
+
+
+def test_prefix_length_parity(oracle, dcn):
+    rng = np.random.default_rng(9)
+    reads = random_reads(rng, 100, 20, 400, p_n=0.002)
+    idx = dcn.Index.from_keys(np.arange(1, 10, dtype=np.uint64), 31, 15)
+    proc = dcn.FilterProcessor(idx, max_batch_bases=1 << 20, max_batch_reads=1024)
+    b, o = oracle.concat_reads(reads)
+    for pl in (6, 45, 100, 1000):
+        off, h, p = proc.minimizer_hashes_batch(b, o, prefix_length=pl)
+        for r, s in enumerate(reads):
+            wh, wp = oracle.minimizer_hashes_and_positions(s, 31, 15, prefix_length=pl)
+            lo, hi = int(off[r]), int(off[r + 1])
+            assert p[lo:hi].tolist() == wp.tolist() and h[lo:hi].tolist() == wh.tolist()
+
+
+def test_golden_vectors_on_gpu(dcn):
+    vec = json.load(open(os.path.join(GOLDEN, "oracle_vectors.json")))["vectors"]
+    procs = {}
+    for v in vec:
+        key = (v["k"], v["w"])
+        if key not in procs:
+            idx = dcn.Index.from_keys(np.arange(1, 3, dtype=np.uint64), *key)
+            procs[key] = dcn.FilterProcessor(idx, max_batch_bases=1 << 16, max_batch_reads=16)
+        h, p = dcn.get_minimizer_hashes_and_positions(procs[key], v["seq"].encode())
+        assert [int(x) for x in p] == v["positions"]
+        assert [hex(int(x)) for x in h] == v["hashes"]
+
+
+def test_tile_seams(oracle, dcn, monkeypatch):
+    """Tiny tiles: every seam position / carry window / dedup across tiles is exercised."""
+    rng = np.random.default_rng(21)
+    reads = random_reads(rng, 40, 40, 1500, p_n=0.002) + [b"ACGT" * 200, b"A" * 500, b"GCATGCAT" * 100]
+    idx = dcn.Index.from_keys(np.arange(1, 10, dtype=np.uint64), 31, 15)
+    b, o = oracle.concat_reads(reads)
+    for tw in ("16", "17", "64", "100"):
+        monkeypatch.setenv("DCN_TILE_WINDOWS", tw)
+        proc = dcn.FilterProcessor(idx, max_batch_bases=1 << 20, max_batch_reads=1024)
+        off, h, p = proc.minimizer_hashes_batch(b, o)
+        for r, s in enumerate(reads):
+            wh, wp = oracle.minimizer_hashes_and_positions(s, 31, 15)
+            lo, hi = int(off[r]), int(off[r + 1])
+            assert p[lo:hi].tolist() == wp.tolist(), (tw, r)
+            assert h[lo:hi].tolist() == wh.tolist(), (tw, r)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the reference's behavioural tests, on the GPU
+# ------------------------------------------------------------------------------------------------------
+CASES = json.load(open(os.path.join(GOLDEN, "reference_cases.json")))["cases"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["id"] for c in CASES])
+def test_reference_cases_on_gpu(oracle, dcn, case):
+    oidx, gidx = make_index_pair(oracle, dcn, [s.encode() for s in case["ref"]], k=case["k"], w=case["w"])
+    proc = dcn.FilterProcessor(gidx, abs_threshold=case["abs"], rel_threshold=case["rel"],
+                               prefix_length=case.get("prefix_length", 0), deplete=case["deplete"],
+                               max_batch_bases=1 << 16, max_batch_reads=64)
+    reads, uid = [], []
+    for u, unit in enumerate(case["units"]):
+        for s in unit:
+            reads.append(s.encode())
+            uid.append(u)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads, np.array(uid, np.uint32))
+    assert keep.tolist() == case["expect_keep"]
+
+
+# ------------------------------------------------------------------------------------------------------
+# whole path: decisions, hits, totals
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("deplete,abs_t,rel_t", [(False, 2, 0.01), (True, 2, 0.01), (False, 1, 0.0), (True, 5, 0.3)])
+def test_filter_short_reads(oracle, dcn, genome, index_pair, deplete, abs_t, rel_t):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(31)
+    reads = sample_reads(rng, genome, 20_000, 30, 250)
+    reads[5] = b""
+    reads[6] = b"ACGT"
+    proc = dcn.FilterProcessor(gidx, abs_threshold=abs_t, rel_threshold=rel_t, deplete=deplete,
+                               max_batch_bases=1 << 23, max_batch_reads=1 << 15)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert 0.2 < keep.mean() < 0.8
+
+
+def test_filter_paired(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(32)
+    reads = sample_reads(rng, genome, 10_001, 100, 151)  # odd count: last unit is a single read
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32)
+    # identical mates: shared minimizers must be counted once
+    reads[10] = reads[11] = genome[5000:5150]
+    for deplete in (False, True):
+        proc = dcn.FilterProcessor(gidx, deplete=deplete, max_batch_bases=1 << 22, max_batch_reads=1 << 14)
+        keep, hits, total = check_batch(oracle, proc, oidx, reads, uid)
+        assert total[5] == 2 * len(oracle.minimizer_hashes_and_positions(reads[10], 31, 15)[0])
+        assert hits[5] * 2 <= total[5] + 1
+    # triples and ragged unit sizes are legal too
+    uid3 = np.repeat(np.arange(4000, dtype=np.uint32), 3)[:len(reads)]
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 22, max_batch_reads=1 << 14)
+    check_batch(oracle, proc, oidx, reads, uid3)
+
+
+def test_filter_long_reads(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(33)
+    lens = np.clip(rng.lognormal(8.0, 0.8, 150).astype(int), 200, 60_000)
+    reads = []
+    for ln in lens:
+        if rng.random() < 0.5:
+            s = int(rng.integers(0, len(genome) - ln))
+            reads.append(mutate(rng, genome[s:s + ln], 0.05))
+        else:
+            reads.append(random_reads(rng, 1, ln, ln)[0])
+    reads += sample_reads(rng, genome, 500, 100, 200)  # mixed with short reads in the same waves
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 23, max_batch_reads=1 << 12)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert hits.max() > 300
+
+
+def test_repeats_inside_long_reads_are_counted_once(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    seg = genome[1000:3000]
+    reads = [seg * 4, seg + revcomp(seg) + seg, genome[0:8000] + genome[4000:12000]]
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 20, max_batch_reads=64)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert total[0] > 3 * hits[0]
+
+
+def test_low_complexity_and_list_overflow(oracle, dcn):
+    """Periodic reads emit a position for nearly every window: per-lane lists and the LDS hit buffer overflow."""
+    units = [b"ACGT" * 60, b"A" * 250, b"AT" * 120, b"GGGCCC" * 40, b"GCATGCAT" * 35, b"ACGTTGCA" * 30]
+    oidx, gidx = make_index_pair(oracle, dcn, units)
+    rng = np.random.default_rng(34)
+    reads = []
+    for _ in range(3000):
+        u = units[int(rng.integers(0, len(units)))]
+        s = int(rng.integers(0, 20))
+        reads.append(u[s:s + int(rng.integers(60, 220))])
+    proc = dcn.FilterProcessor(gidx, abs_threshold=1, max_batch_bases=1 << 21, max_batch_reads=1 << 12)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert total.max() > 100
+
+
+def test_all_host_reads_fill_the_hit_buffer(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(35)
+    reads = sample_reads(rng, genome, 4096, 240, 250, host_frac=1.0, sub=0.0, p_n=0.0)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 21, max_batch_reads=1 << 12)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert hits.min() >= 10 and keep.all()
+
+
+def test_record_scratch_grows(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    # long host reads: ~1 hit record per 8 bases, far more than a small context reserves
+    reads = [genome[i * 20_000:(i + 1) * 20_000 + 5000] for i in range(9)]
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 18, max_batch_reads=16)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert hits.sum() > (1 << 16) // 8
+    s = proc.stats()
+    assert s["total_seqs"] == len(reads)  # the overflowed attempt was not counted twice
+
+
+def test_empty_and_ragged_batches(oracle, dcn, index_pair):
+    oidx, gidx = index_pair
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 16, max_batch_reads=256)
+    keep, hits, total = proc.filter_reads([])
+    assert len(keep) == 0
+    reads = [b"", b"", b"A", b"ACGT" * 7, b"", b"ACGT" * 11, b"N" * 80, b""]
+    for deplete in (False, True):
+        proc.deplete = deplete
+        keep, hits, total = check_batch(oracle, proc, oidx, reads)
+        assert total.tolist()[:5] == [0] * 5 and keep.tolist() == [deplete] * len(reads)
+    with pytest.raises(dcn.DeaconHipError):
+        proc.filter_reads([b"A" * 100] * 300)  # more reads than the context allows
+    with pytest.raises(dcn.DeaconHipError):
+        proc.filter_batch(np.zeros(10, np.uint8), np.array([0, 5, 3], np.uint64))  # offsets not monotone
+
+
+def test_stats_counters(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(36)
+    reads = sample_reads(rng, genome, 3000, 50, 200)
+    proc = dcn.FilterProcessor(gidx, deplete=True, max_batch_bases=1 << 21, max_batch_reads=1 << 12)
+    keep1, _, _ = proc.filter_reads(reads)
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32)
+    b, o = oracle.concat_reads(reads)
+    keep2, _, _ = proc.filter_batch(b, o, uid)
+    lens = np.array([len(r) for r in reads])
+    plen = np.add.reduceat(lens, np.arange(0, len(reads), 2))
+    s = proc.stats()
+    assert s["total_seqs"] == 2 * len(reads)
+    assert s["total_bp"] == 2 * lens.sum()
+    assert s["output_bp"] == lens[keep1].sum() + plen[keep2].sum()
+    assert s["filtered_bp"] == lens[~keep1].sum() + plen[~keep2].sum()
+    assert s["filtered_seqs"] == (~keep1).sum() + 2 * (~keep2).sum()
+    assert s["output_seq_counter"] == keep1.sum() + 2 * keep2.sum()
+    summ = proc.summary(2.0)
+    assert summ["seqs_in"] == s["total_seqs"] and summ["bp_per_second"] == s["total_bp"] // 2
+    proc.reset_stats()
+    assert sum(proc.stats().values()) == 0
+
+
+def test_should_keep_hashes_seam(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(37)
+    reads = sample_reads(rng, genome, 2000, 50, 3000)
+    hs = [oracle.minimizer_hashes_and_positions(r, 31, 15)[0] for r in reads]
+    off = np.concatenate([[0], np.cumsum([len(h) for h in hs])]).astype(np.uint64)
+    flat = np.concatenate(hs)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 16, max_batch_reads=1 << 12)
+    for deplete in (False, True):
+        want = oracle.should_keep_hashes(oidx, flat, off, 2, 0.01, deplete)
+        proc.deplete = deplete
+        got = proc.should_keep_hashes(flat, off)
+        for g, w_ in zip(got, want):
+            assert g.tolist() == w_.tolist()
+    res = dcn.unpaired_should_keep(proc, hs[:50], 2, 0.01, False)
+    want = oracle.should_keep_hashes(oidx, np.concatenate(hs[:50]), off[:51], 2, 0.01, False)
+    assert [r[0] for r in res] == want[0].tolist() and [r[1] for r in res] == want[1].tolist()
+    pairs = [np.concatenate([hs[2 * i], hs[2 * i + 1]]) for i in range(25)]
+    res = dcn.paired_should_keep(proc, pairs, 2, 0.01, True)
+    poff = np.concatenate([[0], np.cumsum([len(x) for x in pairs])]).astype(np.uint64)
+    want = oracle.should_keep_hashes(oidx, np.concatenate(pairs), poff, 2, 0.01, True)
+    assert [r[0] for r in res] == want[0].tolist() and [r[2] for r in res] == want[2].tolist()
+
+
+def test_single_read_seam(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 16, max_batch_reads=16)
+    r = genome[7000:7150]
+    keep, hits, total = proc.should_keep_sequence(r)
+    assert (keep, hits) == (True, total) and total > 5
+    assert proc.should_keep_sequence(revcomp(r)) == (keep, hits, total)
+    kp, hp, tp = proc.should_keep_pair(r, revcomp(r))
+    assert (kp, hp, tp) == (True, hits, 2 * total)
+
+
+def test_device_resident_inputs(oracle, dcn, genome, index_pair):
+    torch = pytest.importorskip("torch")
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(38)
+    reads = sample_reads(rng, genome, 5000, 100, 151)
+    b, o = oracle.concat_reads(reads)
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32)
+    proc = dcn.FilterProcessor(gidx, deplete=True, max_batch_bases=1 << 21, max_batch_reads=1 << 13)
+    dev = torch.device("cuda:0")
+    d_b = torch.from_numpy(b).to(dev)
+    d_o = torch.from_numpy(o.view(np.int64)).to(dev)
+    d_u = torch.from_numpy(uid.view(np.int32)).to(dev)
+    for unit, n_units in ((None, len(reads)), (d_u, int(uid[-1]) + 1)):
+        d_keep = torch.zeros(n_units, dtype=torch.uint8, device=dev)
+        d_hits = torch.zeros(n_units, dtype=torch.int32, device=dev)
+        d_total = torch.zeros(n_units, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        proc.filter_batch_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(b), d_keep.data_ptr(),
+                                 d_hits.data_ptr(), d_total.data_ptr(),
+                                 d_unit_id=unit.data_ptr() if unit is not None else None, n_units=n_units)
+        proc.synchronize()
+        want = oracle.filter_batch(oidx, b, o, None if unit is None else uid, deplete=True, threads=4)
+        assert d_keep.cpu().numpy().astype(bool).tolist() == want[0].tolist()
+        assert d_hits.cpu().numpy().tolist() == want[1].tolist()
+        assert d_total.cpu().numpy().tolist() == want[2].tolist()
+
+
+# ------------------------------------------------------------------------------------------------------
+# size-independent properties at a larger size (no oracle pass over the full input)
+# ------------------------------------------------------------------------------------------------------
+def test_properties_at_scale(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(39)
+    n = 400_000
+    g = np.frombuffer(genome, dtype=np.uint8)
+    starts = rng.integers(0, len(genome) - 150, n)
+    host = rng.random(n) < 0.5
+    mat = g[starts[:, None] + np.arange(150)[None, :]].copy()
+    rnd = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, 150))]
+    mat[~host] = rnd[~host]
+    bases = mat.reshape(-1)
+    offsets = (np.arange(n + 1, dtype=np.uint64) * np.uint64(150))
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=n * 150, max_batch_reads=n)
+    keep, hits, total = proc.filter_batch(bases, offsets)
+    # idempotence
+    keep2, hits2, total2 = proc.filter_batch(bases, offsets)
+    assert (keep == keep2).all() and (hits == hits2).all() and (total == total2).all()
+    # strand symmetry: the reverse complement of every read has the same minimizer multiset
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    rc = comp[mat[:, ::-1]].reshape(-1)
+    keep3, hits3, total3 = proc.filter_batch(rc, offsets)
+    assert (hits == hits3).all() and (total == total3).all() and (keep == keep3).all()
+    # batch-split invariance: any split of the batch gives the same per-read results
+    cut = 123_457
+    a = proc.filter_batch(bases[:cut * 150], offsets[:cut + 1])
+    b = proc.filter_batch(bases[cut * 150:], offsets[cut:] - offsets[cut])
+    assert (np.concatenate([a[1], b[1]]) == hits).all() and (np.concatenate([a[0], b[0]]) == keep).all()
+    # pairing: a pair's total is the sum of its mates' totals, its hits at most the sum and at least the max
+    uid = (np.arange(n) // 2).astype(np.uint32)
+    kp, hp, tp = proc.filter_batch(bases, offsets, uid)
+    assert (tp == total[0::2] + total[1::2]).all()
+    assert (hp <= hits[0::2] + hits[1::2]).all() and (hp >= np.maximum(hits[0::2], hits[1::2])).all()
+    # host reads are (almost all) hit, random reads are not; and a sampled slice matches the oracle exactly
+    assert hits[host].mean() > 8 and hits[~host].max() <= 1
+    sl = slice(200_000, 203_000)
+    want = oracle.filter_batch(oidx, bases[sl.start * 150:sl.stop * 150], offsets[:3001], threads=4)
+    assert want[1].tolist() == hits[sl].tolist() and want[2].tolist() == total[sl].tolist()

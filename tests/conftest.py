@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # PyTorch bundles its own HIP runtime (same SONAME as /opt/rocm's): whichever library is loaded first
+    import torch  # noqa: F401  decides which runtime the process uses, so load torch before libdeacon_hip.so
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -111,7 +111,7 @@ def test_index_from_file(oracle, dcn, tmp_path, genome):
 # ------------------------------------------------------------------------------------------------------
 # K1-K3: minimizer positions and hashes
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("k,w", [(31, 15), (15, 11), (41, 15), (5, 5), (31, 1), (21, 9), (32, 15), (33, 15), (56, 2)])
+@pytest.mark.parametrize("k,w", [(31, 15), (15, 11), (41, 15), (5, 5), (31, 1), (21, 9), (32, 16), (33, 15), (56, 2)])
 def test_minimizer_hashes_and_positions_parity(oracle, dcn, k, w):
     rng = np.random.default_rng(k * 1000 + w)
     reads = random_reads(rng, 300, 0, 700, p_n=0.003, p_lower=0.05)

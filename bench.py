@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mbp/s filtered (k=31, w=15) against a panhuman-1-sized index on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path (pack -> plan -> scan/hash/probe/distinct -> finish) over one batch of
+synthetic 150 bp reads that is already resident in HBM as ASCII + offsets (BASELINE.json configs[1]).  The index is
+a device table of 409,913,780 synthetic u64 keys (panhuman-1's size): the minimizers of a synthetic "host" genome
+plus uniform random keys; half of the reads are drawn from the host genome (0.5 % substitutions, 0.1 % N), half
+are random.  Weak scaling: every rank holds a full index replica and filters its own batch; the only collective
+is the all-reduce of the six summary counters (RCCL) at the end of the timed region.
+
+Prints ONE JSON line on rank 0 (see the task contract): value = whole-job Mbp/s, plus
+  roofline      dominant kernel (scan) : algorithmic HBM bytes / HIP-event time on the kernel's own stream
+  cpu_baseline  the CPU oracle (oracle/, "port") on a bounded sample of the same reads, all host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # first: libdeacon_hip.so must bind to the HIP runtime torch already loaded
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import deacon_server_amd as dcn  # noqa: E402
+
+K, W = 31, 15
+READ_LEN = 150
+PANHUMAN_KEYS = 409_913_780  # README.md:52 of the reference
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_host_genome(n, seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    return alpha[torch.randint(0, 4, (n,), generator=g, device=device)]
+
+
+def host_minimizer_keys(genome_dev, index_k, index_w):
+    """Minimizer hashes of the host genome, computed by the product path itself (dump seam): for ACGT-only
+    sequence the index-side and filter-side rules coincide."""
+    genome = genome_dev.cpu().numpy()
+    seg, ov = 1 << 20, index_k + index_w - 2
+    tmp_idx = dcn.Index.from_keys(np.arange(1, 3, dtype=np.uint64), index_k, index_w, device=genome_dev.device.index)
+    proc = dcn.FilterProcessor(tmp_idx, max_batch_bases=(seg + ov) * 4, max_batch_reads=8)
+    keys = []
+    starts = list(range(0, len(genome), seg))
+    for i in range(0, len(starts), 4):
+        reads = [genome[s:min(len(genome), s + seg + ov)] for s in starts[i:i + 4]]
+        offsets = np.zeros(len(reads) + 1, np.uint64)
+        np.cumsum([len(r) for r in reads], out=offsets[1:])
+        _, h, _ = proc.minimizer_hashes_batch(np.concatenate(reads), offsets)
+        keys.append(np.unique(h))
+    proc.close()
+    tmp_idx.close()
+    return np.unique(np.concatenate(keys))
+
+
+def make_reads(genome_dev, n_reads, seed, device, host_frac=0.5, sub=0.005, p_n=0.001):
+    """n_reads x READ_LEN ASCII on the device: host-derived (with substitutions / N) or uniform random."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty((n_reads, READ_LEN), dtype=torch.uint8, device=device)
+    ar = torch.arange(READ_LEN, device=device)
+    chunk = 1 << 19
+    for a in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - a)
+        is_host = torch.rand(m, generator=g, device=device) < host_frac
+        starts = torch.randint(0, genome_dev.numel() - READ_LEN, (m,), generator=g, device=device)
+        host = genome_dev[starts[:, None] + ar[None, :]]
+        rnd = alpha[torch.randint(0, 4, (m, READ_LEN), generator=g, device=device)]
+        mut = torch.rand((m, READ_LEN), generator=g, device=device) < sub
+        host = torch.where(mut, rnd, host)
+        nmask = torch.rand((m, READ_LEN), generator=g, device=device) < p_n
+        host = torch.where(nmask, torch.full_like(host, ord("N")), host)
+        out[a:a + m] = torch.where(is_host[:, None], host, rnd)
+    return out.reshape(-1)
+
+
+def cpu_baseline(keys, bases_np, n_reads_total, params, want_keep_dev, seconds_target=15.0):
+    """Time the CPU oracle (all host cores) on a bounded sample of the same reads and check the GPU's decisions
+    on that sample against it."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t0 = time.time()
+    oidx = O.Index(keys, K, W, threads=cores)
+    log(f"cpu_baseline: built the {len(oidx):,}-key CPU set with {cores} threads in {time.time() - t0:.1f} s")
+
+    def run(n):
+        off = np.arange(n + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+        t = time.time()
+        res = O.filter_batch(oidx, bases_np[:n * READ_LEN], off, None, params["abs"], params["rel"], 0,
+                             params["deplete"], threads=cores)
+        return time.time() - t, res
+
+    probe_n = min(20_000 * cores, n_reads_total)
+    dt, _ = run(probe_n)
+    rate = probe_n / max(dt, 1e-6)
+    n = int(min(n_reads_total, max(probe_n, rate * seconds_target)))
+    dt, (keep, hits, total) = run(n)
+    ok = bool((want_keep_dev[:n].cpu().numpy().astype(bool) == keep).all())
+    return {
+        "value": n * READ_LEN / dt / 1e6, "unit": "Mbp/s", "cores": cores, "kind": "port",
+        "sample": f"first {n} reads of the rank-0 batch ({n * READ_LEN / 1e6:.1f} Mbp, {dt:.1f} s), oracle/ C restatement "
+                  f"with a pthread pool, same {len(oidx):,}-key index",
+        "decisions_match_gpu": ok,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=4_000_000, help="reads per batch per GPU (150 bp each)")
+    ap.add_argument("--index-keys", type=int, default=PANHUMAN_KEYS)
+    ap.add_argument("--host-genome", type=int, default=16_000_000, help="bases of the synthetic host genome")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    # ---- index: host-genome minimizers + uniform random keys, identical on every rank -----------------------
+    t0 = time.time()
+    genome_dev = make_host_genome(args.host_genome, 3, device)
+    host_keys = host_minimizer_keys(genome_dev, K, W)
+    rng = np.random.default_rng(4)
+    n_rand = max(0, args.index_keys - len(host_keys))
+    keys = np.empty(len(host_keys) + n_rand, np.uint64)
+    keys[:len(host_keys)] = host_keys
+    keys[len(host_keys):] = rng.integers(1, 2**63, n_rand, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    log(f"index keys: {len(host_keys):,} host + {n_rand:,} random in {time.time() - t0:.1f} s")
+    t0 = time.time()
+    index = dcn.Index.from_keys(keys, K, W, device=local_rank)
+    index_build_s = time.time() - t0
+    log(f"device table: {index.n_keys:,} distinct keys in {index_build_s:.1f} s")
+
+    # ---- reads: resident in HBM before the timed region -------------------------------------------------------
+    n_reads = args.reads
+    n_bases = n_reads * READ_LEN
+    d_bases = make_reads(genome_dev, n_reads, 5 + rank, device)
+    d_offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * READ_LEN
+    d_keep = torch.zeros(n_reads, dtype=torch.uint8, device=device)
+    d_hits = torch.zeros(n_reads, dtype=torch.int32, device=device)
+    d_total = torch.zeros(n_reads, dtype=torch.int32, device=device)
+    params = {"abs": 2, "rel": 0.01, "deplete": False}
+    proc = dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"],
+                               deplete=params["deplete"], max_batch_bases=n_bases, max_batch_reads=n_reads)
+    torch.cuda.synchronize()
+
+    def step():
+        proc.filter_batch_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, d_keep.data_ptr(),
+                                 d_hits.data_ptr(), d_total.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    proc.synchronize()
+    proc.reset_stats()
+    proc.set_profiling(True)
+
+    # ---- timed region: exactly K steps, barrier + device sync on both sides ------------------------------------------
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    proc.synchronize()
+    stats = proc.stats()
+    counters = torch.tensor([stats[n] for n in dcn._native.STAT_NAMES], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)  # RCCL: the path's only collective (C1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    counters = counters.cpu().tolist()
+
+    stage_ms, n_prof = proc.profile()
+    proc.set_profiling(False)
+    n_minimizers = int(d_total.sum(dtype=torch.int64).item())
+    kept = int(d_keep.sum(dtype=torch.int64).item())
+
+    if rank == 0:
+        total_bp = counters[2]
+        assert total_bp == n_bases * args.steps * world, (total_bp, n_bases, args.steps, world)
+        scan_ms = stage_ms["scan"] / max(n_prof, 1)
+        algo_bytes = 0.375 * n_bases + 8.0 * n_minimizers  # 2-bit base + mask bit, 8 B per probe
+        achieved = algo_bytes / (scan_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mbp/s filtered (k=31,w=15 vs panhuman-1-sized index), decisions bit-exact vs CPU",
+            "value": total_bp / elapsed / 1e6,
+            "unit": "Mbp/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32/u64 integer",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
+                "index_keys": int(index.n_keys), "reads_per_batch_per_gpu": n_reads, "read_len": READ_LEN,
+                "k": K, "w": W, "host_fraction": 0.5, "parallelism": f"reads sharded x{world}, index replicated",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "scan_kernel<15> (scan+hash+probe+distinct)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_ms,
+                "minimizers_per_launch": n_minimizers,
+            },
+            "stage_ms_per_step": {k_: v / max(n_prof, 1) for k_, v in stage_ms.items()},
+            "kept_fraction": kept / n_reads,
+            "index_build_s": index_build_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            bases_np = d_bases[:min(n_reads, 2_000_000) * READ_LEN].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(keys, bases_np, min(n_reads, 2_000_000), params, d_keep)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,6 +20,8 @@ DCN_ERR_FORMAT = -5
 DCN_ERR_CAPACITY = -6
 DCN_ERR_INTERNAL = -7
 N_STATS = 6
+N_STAGES = 5
+STAGE_NAMES = ("pack", "plan", "scan", "distinct", "finish")
 STAT_NAMES = ("total_seqs", "filtered_seqs", "total_bp", "output_bp", "filtered_bp", "output_seq_counter")
 
 
@@ -81,6 +83,8 @@ _SIGNATURES = {
     "dcn_should_keep_hashes": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp]),
     "dcn_ctx_stats": (C.c_int, [_vp, _u64p]),
     "dcn_ctx_reset_stats": (C.c_int, [_vp]),
+    "dcn_ctx_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "dcn_ctx_profile": (C.c_int, [_vp, C.POINTER(C.c_double), _u64p]),
 }
 
 _lib = None

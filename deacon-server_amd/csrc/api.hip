@@ -158,6 +158,14 @@ struct dcn_ctx {
     uint8_t *d_dump_valid = nullptr;
     // deferred state of the last enqueued batch
     bool batch_pending = false;
+    // optional per-stage timing: a ring of event sets, one per batch in flight
+    static constexpr int PROF_RING = 32;
+    bool profiling = false;
+    hipEvent_t prof_ev[PROF_RING][DCN_N_STAGES + 1] = {};
+    bool prof_used[PROF_RING] = {};
+    int prof_next = 0;
+    double prof_ms[DCN_N_STAGES] = {};
+    uint64_t prof_batches = 0;
 };
 
 namespace {
@@ -214,11 +222,49 @@ void free_ctx(dcn_ctx *c) {
         if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
     }
     if (c->h_status) hipHostFree(c->h_status);
+    for (int i = 0; i < dcn_ctx::PROF_RING; ++i)
+        for (int j = 0; j <= DCN_N_STAGES; ++j)
+            if (c->prof_ev[i][j]) hipEventDestroy(c->prof_ev[i][j]);
     if (c->copy_done) hipEventDestroy(c->copy_done);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     delete c;
 }
+
+// fold the event pairs of every completed batch into the per-stage accumulators
+int prof_harvest(dcn_ctx *c, int only_slot = -1) {
+    for (int i = 0; i < dcn_ctx::PROF_RING; ++i) {
+        if (!c->prof_used[i] || (only_slot >= 0 && i != only_slot)) continue;
+        DCN_HIP(hipEventSynchronize(c->prof_ev[i][DCN_N_STAGES]));
+        for (int j = 0; j < DCN_N_STAGES; ++j) {
+            float ms = 0.f;
+            DCN_HIP(hipEventElapsedTime(&ms, c->prof_ev[i][j], c->prof_ev[i][j + 1]));
+            c->prof_ms[j] += ms;
+        }
+        c->prof_batches++;
+        c->prof_used[i] = false;
+    }
+    return DCN_OK;
+}
+
+// returns the event slot for this batch (or -1 when profiling is off) after recording its first event
+int prof_begin(dcn_ctx *c, int *slot) {
+    *slot = -1;
+    if (!c->profiling) return DCN_OK;
+    int i = c->prof_next;
+    c->prof_next = (i + 1) % dcn_ctx::PROF_RING;
+    if (c->prof_used[i]) DCN_TRY(prof_harvest(c, i));
+    for (int j = 0; j <= DCN_N_STAGES; ++j)
+        if (!c->prof_ev[i][j]) DCN_HIP(hipEventCreate(&c->prof_ev[i][j]));
+    DCN_HIP(hipEventRecord(c->prof_ev[i][0], c->stream));
+    *slot = i;
+    return DCN_OK;
+}
+
+#define DCN_PROF_MARK(stage)                                                        \
+    do {                                                                            \
+        if (prof_slot >= 0) DCN_HIP(hipEventRecord(c->prof_ev[prof_slot][(stage) + 1], st)); \
+    } while (0)
 
 int check_params(const dcn_params *p) {
     if (!p) return dcn_fail(DCN_ERR_ARG, "params is NULL");
@@ -238,8 +284,11 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     DCN_HIP(hipMemsetAsync(c->d_unit_state, 0, n_units, st));
     DCN_HIP(hipMemsetAsync(c->d_unit_scratch, 0, (uint64_t)c->max_reads * 4 * sizeof(uint32_t), st));
 
+    int prof_slot = -1;
+    DCN_TRY(prof_begin(c, &prof_slot));
     uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
     DCN_TRY(dcn_launch_pack(d_bases, n_bases, packed, invmask, st));
+    DCN_PROF_MARK(DCN_STAGE_PACK);
 
     dcn_plan_args pa;
     pa.ascii = d_bases;
@@ -261,6 +310,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     DCN_TRY(dcn_launch_plan_reads(pa, st));
     DCN_TRY(dcn_launch_exclusive_scan(c->d_read_tiles, c->d_read_tile_first, n_reads, c->d_scan_tmp, st));
     DCN_TRY(dcn_launch_plan_tiles(pa, st));
+    DCN_PROF_MARK(DCN_STAGE_PLAN);
 
     uint32_t *g_total = c->d_unit_scratch, *g_hitcnt = g_total + c->max_reads, *g_distinct = g_hitcnt + c->max_reads,
              *g_zero = g_distinct + c->max_reads;
@@ -290,6 +340,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     uint64_t tile_bound = (uint64_t)n_reads + n_bases / c->tile_windows + 1;
     if (tile_bound > c->max_tiles) tile_bound = c->max_tiles;
     DCN_TRY(dcn_launch_scan(sa, (uint32_t)tile_bound, false, st));
+    DCN_PROF_MARK(DCN_STAGE_SCAN);
 
     dcn_distinct_args da;
     da.rec_unit = c->d_rec_unit;
@@ -304,6 +355,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     da.n_units = n_units;
     da.status = c->d_status;
     DCN_TRY(dcn_launch_distinct(da, c->d_caps, c->d_scan_tmp, st));
+    DCN_PROF_MARK(DCN_STAGE_DISTINCT);
 
     dcn_finish_args fa;
     fa.n_units = n_units;
@@ -321,6 +373,8 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     fa.status_stats = c->d_status->stats;
     fa.status = c->d_status;
     DCN_TRY(dcn_launch_finish(fa, st));
+    DCN_PROF_MARK(DCN_STAGE_FINISH);
+    if (prof_slot >= 0) c->prof_used[prof_slot] = true;
     c->batch_pending = true;
     return DCN_OK;
 }
@@ -329,6 +383,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
 int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     DCN_HIP(hipStreamSynchronize(c->stream));
     if (needed_records) *needed_records = 0;
+    if (c->profiling) DCN_TRY(prof_harvest(c));
     if (!c->batch_pending) return DCN_OK;
     c->batch_pending = false;
     DCN_HIP(hipMemcpy(c->h_status, c->d_status, sizeof(dcn_status), hipMemcpyDeviceToHost));
@@ -525,6 +580,24 @@ extern "C" int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64
     DCN_HIP(hipMemcpy(keep, ctx->d_keep, n_units, hipMemcpyDeviceToHost));
     if (hits) DCN_HIP(hipMemcpy(hits, ctx->d_hits, (uint64_t)n_units * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (total) DCN_HIP(hipMemcpy(total, ctx->d_total, (uint64_t)n_units * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return DCN_OK;
+}
+
+extern "C" int dcn_ctx_set_profiling(dcn_ctx *ctx, int enable) {
+    if (!ctx) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
+    DCN_HIP(hipSetDevice(ctx->device));
+    DCN_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < dcn_ctx::PROF_RING; ++i) ctx->prof_used[i] = false;
+    for (int j = 0; j < DCN_N_STAGES; ++j) ctx->prof_ms[j] = 0.0;
+    ctx->prof_batches = 0;
+    ctx->profiling = enable != 0;
+    return DCN_OK;
+}
+
+extern "C" int dcn_ctx_profile(dcn_ctx *ctx, double stage_ms[DCN_N_STAGES], uint64_t *n_batches) {
+    if (!ctx || !stage_ms) return dcn_fail(DCN_ERR_ARG, "ctx/stage_ms is NULL");
+    for (int j = 0; j < DCN_N_STAGES; ++j) stage_ms[j] = ctx->prof_ms[j];
+    if (n_batches) *n_batches = ctx->prof_batches;
     return DCN_OK;
 }
 

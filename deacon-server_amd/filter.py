@@ -177,6 +177,16 @@ class FilterProcessor:
     def reset_stats(self):
         N.check(N.lib().dcn_ctx_reset_stats(self._h))
 
+    def set_profiling(self, enable=True):
+        N.check(N.lib().dcn_ctx_set_profiling(self._h, 1 if enable else 0))
+
+    def profile(self):
+        """-> ({stage: accumulated device ms}, batches measured); HIP events on the context's stream."""
+        ms = (C.c_double * N.N_STAGES)()
+        n = C.c_uint64()
+        N.check(N.lib().dcn_ctx_profile(self._h, ms, C.byref(n)))
+        return dict(zip(N.STAGE_NAMES, (float(x) for x in ms))), int(n.value)
+
     def summary(self, elapsed_seconds):
         """The numeric fields of FilterSummary (filter_common.rs:11-38; filled at local_filter.rs:780-821)."""
         s = self.stats()

@@ -154,6 +154,25 @@ int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, const uint64_t 
 int dcn_ctx_stats(dcn_ctx *ctx, uint64_t counters[DCN_N_STATS]);
 int dcn_ctx_reset_stats(dcn_ctx *ctx);
 
+/* ---- measurement ------------------------------------------------------------------------------------ */
+
+/* Stages of one batch on the context's stream, timed with HIP events recorded on that stream. */
+enum {
+    DCN_STAGE_PACK = 0,     /* ASCII -> 2-bit stream + invalid mask */
+    DCN_STAGE_PLAN = 1,     /* effective lengths, prefix sum, tile descriptors */
+    DCN_STAGE_SCAN = 2,     /* minimizer scan + k-mer hash + index probe + in-wave distinct count (dominant) */
+    DCN_STAGE_DISTINCT = 3, /* exact distinct count for units spanning several waves */
+    DCN_STAGE_FINISH = 4,   /* decisions of those units + the six counters */
+    DCN_N_STAGES = 5
+};
+
+/* enable != 0: record events around every stage of every following batch (and clear the accumulators). */
+int dcn_ctx_set_profiling(dcn_ctx *ctx, int enable);
+
+/* Accumulated device time per stage in milliseconds and the number of batches measured, for batches that
+ * have completed (call after dcn_ctx_synchronize). */
+int dcn_ctx_profile(dcn_ctx *ctx, double stage_ms[DCN_N_STAGES], uint64_t *n_batches);
+
 #ifdef __cplusplus
 }
 #endif

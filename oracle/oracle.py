@@ -78,6 +78,8 @@ def lib():
     L.dor_set_len.argtypes = [C.c_void_p]
     L.dor_set_insert_many.restype = C.c_int
     L.dor_set_insert_many.argtypes = [C.c_void_p, u64p, C.c_uint64]
+    L.dor_set_insert_many_mt.restype = C.c_int
+    L.dor_set_insert_many_mt.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int]
     L.dor_set_dump.restype = C.c_uint64
     L.dor_set_dump.argtypes = [C.c_void_p, u64p, C.c_uint64]
     L.dor_count_distinct_hits.restype = C.c_uint64
@@ -183,14 +185,19 @@ def meets_filtering_criteria(hits, total, abs_threshold, rel_threshold, deplete)
 class Index:
     """Stand-in for the reference's FxHashSet<u64> index (membership only)."""
 
-    def __init__(self, keys=(), k=31, w=15):
+    def __init__(self, keys=(), k=31, w=15, threads=1):
         self.k, self.w = k, w
         keys = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64))
         self._h = lib().dor_set_new(max(len(keys), 8))
         if not self._h:
             raise MemoryError
         if len(keys):
-            lib().dor_set_insert_many(self._h, _p(keys, C.c_uint64), len(keys))
+            if threads > 1:
+                rc = lib().dor_set_insert_many_mt(self._h, _p(keys, C.c_uint64), len(keys), threads)
+            else:
+                rc = lib().dor_set_insert_many(self._h, _p(keys, C.c_uint64), len(keys))
+            if rc != 0:
+                raise MemoryError(f"oracle set insert error {rc}")
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -89,11 +89,24 @@ def make_reads(genome_dev, n_reads, seed, device, host_frac=0.5, sub=0.005, p_n=
     return out.reshape(-1)
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box gives a
+    1-GPU job 16 of its 256 hardware threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(keys, bases_np, n_reads_total, params, want_keep_dev, seconds_target=15.0):
     """Time the CPU oracle (all host cores) on a bounded sample of the same reads and check the GPU's decisions
     on that sample against it."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     t0 = time.time()
     oidx = O.Index(keys, K, W, threads=cores)
     log(f"cpu_baseline: built the {len(oidx):,}-key CPU set with {cores} threads in {time.time() - t0:.1f} s")
@@ -105,7 +118,7 @@ def cpu_baseline(keys, bases_np, n_reads_total, params, want_keep_dev, seconds_t
                              params["deplete"], threads=cores)
         return time.time() - t, res
 
-    probe_n = min(20_000 * cores, n_reads_total)
+    probe_n = min(10_000 * cores, n_reads_total)
     dt, _ = run(probe_n)
     rate = probe_n / max(dt, 1e-6)
     n = int(min(n_reads_total, max(probe_n, rate * seconds_target)))
@@ -225,7 +238,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32/u64 integer",
+            "dtype": "u64",
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",

@@ -8,7 +8,7 @@ import re
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libdeacon_hip.so")
+LIB_PATH = os.environ.get("DCN_LIB_PATH") or os.path.join(_PKG, "lib", "libdeacon_hip.so")  # env: experiment builds
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "deacon_hip.h")
 
 DCN_OK = 0
@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dcn_index_from_file": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "dcn_index_header": (C.c_int, [_vp, _u8p, _u8p, _u64p]),
     "dcn_index_contains": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "dcn_index_contains_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
     "dcn_index_destroy": (None, [_vp]),
     "dcn_ctx_create": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
     "dcn_ctx_destroy": (None, [_vp]),

@@ -107,6 +107,13 @@ extern "C" int dcn_index_contains(const dcn_index *index, const uint64_t *keys, 
     return dcn_table_contains(index, keys, n, out);
 }
 
+extern "C" int dcn_index_contains_device(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
+                                         void *stream) {
+    if (!index) return dcn_fail(DCN_ERR_ARG, "index is NULL");
+    if (n > 0 && (!d_keys || !d_out)) return dcn_fail(DCN_ERR_ARG, "d_keys/d_out is NULL");
+    return dcn_table_contains_device(index, d_keys, n, d_out, (hipStream_t)stream);
+}
+
 extern "C" void dcn_index_destroy(dcn_index *index) {
     if (!index) return;
     hipSetDevice(index->device);

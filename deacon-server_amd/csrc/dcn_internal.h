@@ -64,7 +64,6 @@ __host__ __device__ inline uint32_t dcn_group_of(uint64_t key, uint32_t group_sh
 // ----------------------------------------------------------------------------------------------------
 constexpr int DCN_WAVE = 64;           // one wave per workgroup in the scan kernel: 64 tiles
 constexpr int DCN_LCAP = 40;           // per-lane emitted-position list capacity between flushes
-constexpr int DCN_HCAP = 1024;         // per-wave LDS hit-hash capacity before spilling to global records
 constexpr uint32_t DCN_FRONT_PAD = 64; // u32 words of zero padding in front of the packed stream
 constexpr uint32_t DCN_TAIL_PAD = 256; // u32 words after it (lanes over-read past short tiles)
 constexpr uint32_t DCN_MAX_TILE_WINDOWS = 4096;
@@ -124,6 +123,8 @@ int dcn_launch_scan(const dcn_scan_args &args, uint32_t max_tiles, bool dump, hi
 
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);
 int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t n, uint8_t *out);
+int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
+                              hipStream_t stream);
 
 // exclusive prefix sum of n u32 values into out[0..n] (out[n] = total); tmp holds ceil(n/1024)+1 words
 int dcn_launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *d_tmp,

@@ -77,19 +77,28 @@ __device__ inline uint64_t dcn_packed_u64(const uint32_t *packed, uint64_t p) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// hash of the canonical k-mer starting at absolute base p, k <= 32
-__device__ inline uint64_t dcn_kmer_hash64(const uint32_t *packed, uint64_t p, uint32_t k) {
-    uint64_t bits = dcn_packed_u64(packed, p);
+// hash of the canonical k-mer whose 2k bits start at bit 0 of `bits` (upper bits arbitrary), k <= 32
+__device__ inline uint64_t dcn_kmer_hash64_bits(uint64_t bits, uint32_t k) {
     uint32_t sh = 64 - 2 * k;
     uint64_t a = (bits << sh) >> sh;
     uint64_t b = dcn_revcomp64(a) >> sh;
     return dcn_xxh3_u64(a < b ? a : b);
 }
 
+// hash of the canonical k-mer starting at absolute base p, k <= 32
+__device__ inline uint64_t dcn_kmer_hash64(const uint32_t *packed, uint64_t p, uint32_t k) {
+    return dcn_kmer_hash64_bits(dcn_packed_u64(packed, p), k);
+}
+
+__device__ inline uint64_t dcn_kmer_hash128_bits(uint64_t lo, uint64_t hi, uint32_t k);
+
 // hash of the canonical k-mer starting at absolute base p, 32 < k <= 56 (u128 value, 16-byte hash)
 __device__ inline uint64_t dcn_kmer_hash128(const uint32_t *packed, uint64_t p, uint32_t k) {
-    uint64_t lo = dcn_packed_u64(packed, p);
-    uint64_t hi = dcn_packed_u64(packed, p + 32);
+    return dcn_kmer_hash128_bits(dcn_packed_u64(packed, p), dcn_packed_u64(packed, p + 32), k);
+}
+
+// same from the two 64-bit words holding the k-mer's 2k bits (bits above 2k arbitrary)
+__device__ inline uint64_t dcn_kmer_hash128_bits(uint64_t lo, uint64_t hi, uint32_t k) {
     uint32_t hb = 2 * k - 64; // valid bits in the high word, 2..48
     hi &= (~0ull) >> (64 - hb);
     // reverse complement of the 2k-bit value: reverse both words, swap them, shift right by 128-2k

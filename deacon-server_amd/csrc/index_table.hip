@@ -127,3 +127,13 @@ int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t
     hipFree(d_out);
     return rc;
 }
+
+int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
+                              hipStream_t stream) {
+    DCN_HIP(hipSetDevice(idx->device));
+    if (n == 0) return DCN_OK;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(table_contains_kernel, dim3(blocks), dim3(256), 0, stream, idx->view(), d_keys, n, d_out);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
+}

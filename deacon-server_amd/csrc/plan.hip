@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void distinct_insert_kernel(dcn_distinct_args 
 
 // ---- A7/A10: decision for units not resolved by the scan kernel + the six counters ----------------------------
 __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long st[DCN_N_STATS] = {0, 0, 0, 0, 0, 0};
-    if (u < a.n_units) {
+    // grid-stride: few blocks, so the six counters see a few thousand atomics instead of one set per 256 units
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < a.n_units; u += gridDim.x * blockDim.x) {
         uint32_t r0 = a.unit_first_read ? a.unit_first_read[u] : u;
         uint32_t r1 = a.unit_first_read ? a.unit_first_read[u + 1] : u + 1;
         bool keep;
@@ -129,14 +129,14 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
         if (a.offsets) {
             // ProcessingStats, src/local_filter.rs:346-371 (single) / :417-445 (pair)
             unsigned long long nseq = r1 - r0, bp = a.offsets[r1] - a.offsets[r0];
-            st[DCN_STAT_TOTAL_SEQS] = nseq;
-            st[DCN_STAT_TOTAL_BP] = bp;
+            st[DCN_STAT_TOTAL_SEQS] += nseq;
+            st[DCN_STAT_TOTAL_BP] += bp;
             if (keep) {
-                st[DCN_STAT_OUTPUT_BP] = bp;
-                st[DCN_STAT_OUTPUT_SEQ_COUNTER] = nseq;
+                st[DCN_STAT_OUTPUT_BP] += bp;
+                st[DCN_STAT_OUTPUT_SEQ_COUNTER] += nseq;
             } else {
-                st[DCN_STAT_FILTERED_SEQS] = nseq;
-                st[DCN_STAT_FILTERED_BP] = bp;
+                st[DCN_STAT_FILTERED_SEQS] += nseq;
+                st[DCN_STAT_FILTERED_BP] += bp;
             }
         }
     }
@@ -221,7 +221,7 @@ int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *
 }
 
 int dcn_launch_finish(const dcn_finish_args &a, hipStream_t stream) {
-    hipLaunchKernelGGL(finish_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(a.n_units, 1024)), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }

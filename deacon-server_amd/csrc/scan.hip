@@ -10,17 +10,19 @@
 //     cross-lane traffic in the inner loop.  A window's choice depends only on its own l = k+w-1 bases, so
 //     tiles overlap by l-1 bases and are exact; only the consecutive-duplicate rule needs the previous
 //     window's choice, which a non-first tile recomputes from one extra "carry" window.
-//   * phase A (VALU-bound): per base one rolling ntHash32 step (one 16-byte LDS table read), the
-//     two-stack sliding min/max over w keys held in registers (ring index static: the loop is
+//   * phase A: per base one rolling ntHash32 step (one 16-byte LDS table read, issued one step ahead),
+//     the two-stack sliding min/max over w keys held in registers (ring index static: the loop is
 //     unrolled by W), a rolling TG count, and a predicated append of the chosen position to a per-lane
 //     LDS list.  Keys are (h & 0xffff0000) | j: only the top 16 hash bits are compared and ties break
 //     on position, leftmost for TG-rich ("canonical") windows, rightmost otherwise.
-//   * phase B (latency-bound): the wave flattens the 64 lists and handles one emitted minimizer per
-//     lane: ACGT test on the mask bits, canonical k-mer value, XXH3-64, one 32-byte group read of the
-//     HBM-resident set.  Hits are appended to an LDS array grouped by unit.
-//   * units (reads / pairs) whose tiles all sit in this wave are finished here: exact distinct-hit
-//     count over the unit's LDS hits and the -a/-r threshold.  Units spanning waves (long reads)
-//     leave (unit, hash) hit records and per-unit totals in global memory for distinct.hip.
+//   * phase B: the wave flattens the 64 lists and handles one emitted minimizer per lane and round:
+//     ACGT test on the mask bits, canonical k-mer value, XXH3-64, one 32-byte group read of the
+//     HBM-resident set.
+//   * units (reads / pairs) whose tiles all sit in this wave are finished here: hits go through a small LDS
+//     ring in item order (a unit's hits are contiguous), each new hit is compared with the unit's earlier
+//     ones, so the exact distinct count needs no per-wave hit table; then the -a/-r threshold.  Units
+//     spanning waves (long reads) export (unit, hash) hit records and per-unit totals for plan.hip's
+//     distinct pass.
 #include "dcn_internal.h"
 #include "dcn_probe.h"
 
@@ -47,21 +49,37 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+constexpr int DCN_RCAP = 256; // LDS ring of the most recent hits; a unit resolved in-wave has <= RCAP-64 items
+
 struct WaveShared {
-    uint4 tab[16];                      // {F[in], rotl(F[in^2],k-1), rotl(F[out],k-1), F[out^2]} at in | out<<2
+    uint4 tab[16];                      // {F[in], rotl(F[in^2],k-1), rotl(F[out],k), rotr(F[out^2],1)} at in | out<<2
     uint16_t list[DCN_LCAP][DCN_WAVE];  // per-lane emitted positions (relative to the tile's scan start)
-    uint64_t hit_hash[DCN_HCAP];
-    uint8_t hit_unit[DCN_HCAP];
-    uint32_t total[DCN_WAVE];           // per unit slot: minimizers (after the ACGT filter)
+    uint64_t ring_hash[DCN_RCAP];
+    uint8_t ring_unit[DCN_RCAP];
+    uint32_t total[DCN_WAVE];           // per unit slot: emitted minimizers minus those failing the ACGT test
     uint32_t hits[DCN_WAVE];            // per unit slot: distinct hits
+    uint32_t items[DCN_WAVE];           // per unit slot: emitted minimizers (bounds the ring span)
     uint32_t unit_of[DCN_WAVE];         // unit slot -> global unit id
-    uint16_t start[DCN_WAVE + 1];       // exclusive prefix of the per-lane list lengths
-    uint8_t local[DCN_WAVE];            // unit slot is resolved inside this wave
+    uint16_t start[DCN_WAVE + 2];       // exclusive prefix of the per-lane list lengths
+    uint8_t local[DCN_WAVE];            // unit slot has all its tiles in this wave
+    uint8_t lok[DCN_WAVE];              // unit slot is being resolved inside this wave
+};
+
+#ifndef DCN_EXP
+#define DCN_EXP 0 // experiment bits (timing-only builds): 1 = no set probe, 2 = no phase B, 4 = no list store
+#endif
+#ifndef DCN_MIN_WAVES
+#define DCN_MIN_WAVES 4
+#endif
+
+template <bool B>
+struct BoolTag {
+    static constexpr bool value = B;
 };
 
 // W > 0: window size known at compile time, ring in registers.  W == 0: runtime w, ring in dynamic LDS.
 template <int W, bool K128, bool DUMP>
-__global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
+__global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_args a) {
     __shared__ WaveShared sh;
     extern __shared__ uint2 dyn_ring[]; // only for W == 0: [w][64] (lkey, rkey)
 
@@ -86,6 +104,8 @@ __global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
     const uint32_t uslot = (uint32_t)__popcll(head_mask & ((2ull << lane) - 1)) - 1;
     sh.total[lane] = 0;
     sh.hits[lane] = 0;
+    sh.items[lane] = 0;
+    sh.lok[lane] = 0;
     if (head) {
         sh.unit_of[uslot] = t.unit;
         bool loc = false;
@@ -100,27 +120,22 @@ __global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
         uint4 e;
         e.x = NT_F[in];
         e.y = rotl32(NT_F[in ^ 2], (k - 1) & 31);
-        e.z = rotl32(NT_F[out], (k - 1) & 31);
-        e.w = NT_F[out ^ 2];
+        e.z = rotl32(NT_F[out], k & 31);  // rotl(F[out], k-1), pre-rotated by the next step's rotl 1
+        e.w = rotl32(NT_F[out ^ 2], 31);  // F[out^2], pre-rotated by the next step's rotr 1
         sh.tab[lane] = e;
     }
     __syncthreads();
 
-    // ---- stream geometry -----------------------------------------------------------------------------
     const uint32_t *packed = a.packed;
     const int64_t s = (int64_t)t.scan_start;
-    const int64_t q_in = s >> 4;
-    const uint32_t sh_in = (uint32_t)(s & 15) * 2;
-    const int64_t sk = s - (int64_t)(k - 1);
-    const int64_t q_k = sk >> 4; // arithmetic shift: floor
-    const uint32_t sh_k = (uint32_t)(sk & 15) * 2;
-    const int64_t sl = s - (int64_t)(l - 1);
-    const int64_t q_l = sl >> 4;
-    const uint32_t sh_l = (uint32_t)(sl & 15) * 2;
 
     // ---- prologue: first k-1 bases (no complete k-mer yet) -------------------------------------------------
+    // fw / rc hold the hashes BEFORE the removal of the outgoing base; the removal terms of a step are folded
+    // into the next step (zprev / wprev), so one step is two rotates, two 3-input xors and one add.
     uint32_t fw = 0, rc = 0, tg = 0;
     {
+        const int64_t q_in = s >> 4;
+        const uint32_t sh_in = (uint32_t)(s & 15) * 2;
         uint32_t cur = 0;
         for (uint32_t tt = 0; tt + 1 < k; ++tt) {
             if ((tt & 15) == 0) cur = __funnelshift_r(packed[q_in + (tt >> 4)], packed[q_in + (tt >> 4) + 1], sh_in);
@@ -130,56 +145,41 @@ __global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
             rc = rotl32(rc, 31) ^ e.y;
             tg += c >> 1;
         }
-        // the main loop subtracts the TG bit of base t-(l-1) from its first step t=k-1 on; for t < l-1
-        // that is one of the w-1 bases in front of the tile: pre-add them so the subtraction cancels.
-        for (uint32_t b = 1; b < w; ++b) {
-            int64_t p = s - (int64_t)b;
-            tg += (packed[p >> 4] >> (2 * (uint32_t)(p & 15) + 1)) & 1u;
-        }
     }
+    uint32_t zprev = 0, wprev = 0;
 
     // ---- phase A / phase B state --------------------------------------------------------------------------
-    uint32_t cnt = 0;            // entries in this lane's list
-    uint32_t emitted_before = 0; // entries already flushed (dump slot numbering)
-    uint32_t prev = 0xFFFFFFFFu; // previous window's choice (dedup state)
-    uint32_t n_hits = 0;         // wave-uniform: hits held in LDS
-    bool go_global = false;      // wave-uniform: hits/totals of every unit go through global memory
+    uint32_t cnt = 0;              // entries in this lane's list
+    uint32_t emitted_before = 0;   // entries already flushed (not counting a dropped carry entry)
+    bool first_pending = carry;    // a carry tile's first entry only seeds the dedup state: dropped in phase B
+    uint32_t prev = 0xFFFFFFFFu;   // previous window's choice (dedup state)
+    uint32_t n_ring = 0;           // wave-uniform: hits pushed through the LDS ring so far
+    bool go_global = false;        // wave-uniform: no unit of this wave is resolved in-wave any more
     const uint32_t nk = nwc ? nwc + w - 1 : 0;
     const uint32_t jmax = wave_max_u32(nk);
 
-    auto spill_hits = [&]() {
-        // move every LDS hit to the global (unit, hash) record list
-        if (n_hits > 0) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&a.status->rec_count, (unsigned long long)n_hits);
-            base = __shfl(base, 0, 64);
-            for (uint32_t x = lane; x < n_hits; x += DCN_WAVE) {
-                unsigned long long r = base + x;
-                if (r < a.rec_capacity) {
-                    uint32_t u = sh.unit_of[sh.hit_unit[x]];
-                    a.rec_unit[r] = u;
-                    a.rec_hash[r] = sh.hit_hash[x];
-                    atomicAdd(&a.g_hitcnt[u], 1u);
-                } else {
-                    a.status->rec_overflow = 1;
-                }
-            }
+    // Phase B.  Flattens the 64 lists (item e belongs to the lane whose prefix range holds e); one item per lane
+    // and round.
+    auto flush = [&](bool final_flush) {
+        const uint32_t skip0 = (first_pending && cnt > 0) ? 1u : 0u;
+        const uint32_t cnt_eff = cnt - skip0;
+        uint32_t incl = wave_inclusive_scan_u32(cnt_eff, lane);
+        uint32_t M = __shfl(incl, 63, 64);
+        sh.start[lane] = (uint16_t)(incl - cnt_eff);
+        if (lane == 63) sh.start[64] = (uint16_t)M;
+        if (!DUMP && cnt_eff) atomicAdd(&sh.items[uslot], cnt_eff);
+        if (!final_flush) go_global = true; // a unit's hits are contiguous only within one flush
+        __syncthreads();
+        if (!DUMP && head) {
+            // resolved in-wave: all tiles here, single flush, and few enough items for the hit ring
+            bool ok = sh.local[uslot] && !go_global && sh.items[uslot] <= (uint32_t)(DCN_RCAP - DCN_WAVE);
+            sh.lok[uslot] = ok ? 1 : 0;
         }
         __syncthreads();
-        n_hits = 0;
-    };
-
-    auto flush = [&](bool final_flush) {
-        // ---- flatten the 64 lists ------------------------------------------------------------------------
-        uint32_t incl = wave_inclusive_scan_u32(cnt, lane);
-        uint32_t M = __shfl(incl, 63, 64);
-        sh.start[lane] = (uint16_t)(incl - cnt);
-        if (lane == 63) sh.start[64] = (uint16_t)M;
-        __syncthreads();
-        if (!final_flush) go_global = true; // hits of one unit are contiguous only within a flush
-        for (uint32_t E = 0; E < M; E += DCN_WAVE) {
-            uint32_t e = E + lane;
-            bool act = e < M;
+        constexpr int NPW = K128 ? 5 : 3; // packed words per k-mer
+        for (uint32_t E = 0; E < ((DCN_EXP & 2) ? 0u : M); E += DCN_WAVE) {
+            const uint32_t e = E + lane;
+            const bool act = e < M;
             // owner = largest lane whose list starts at or before e
             uint32_t lo = 0, hi = 63;
 #pragma unroll
@@ -189,93 +189,213 @@ __global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
                 lo = le ? mid : lo;
                 hi = le ? hi : mid - 1;
             }
-            uint32_t owner = lo;
-            uint32_t idx = act ? e - sh.start[owner] : 0;
-            uint32_t rel = sh.list[idx][owner];
-            long long o_s = __shfl((long long)s, owner, 64);
-            uint32_t o_uslot = __shfl(uslot, owner, 64);
-            uint64_t p = (uint64_t)(o_s + rel);
-            bool valid = act && dcn_kmer_valid(a.invmask, p, k);
+            const uint32_t owner = lo;
+            const uint32_t idx = act ? e - sh.start[owner] : 0;
+            const uint32_t o_skip = __shfl(skip0, owner, 64);
+            const uint32_t rel = sh.list[idx + o_skip][owner];
+            const long long o_s = __shfl((long long)s, owner, 64);
+            const uint32_t o_uslot = __shfl(uslot, owner, 64);
+            const uint64_t p = (uint64_t)(o_s + rel);
+            uint32_t mw[3], pw[NPW];
+            if (act) {
+                const uint32_t *mp = a.invmask + (p >> 5);
+                const uint32_t *pp = packed + (p >> 4);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) mw[q] = mp[q];
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) pw[q] = pp[q];
+            }
+            bool valid = false;
             uint64_t hash = 0;
-            if (valid) hash = K128 ? dcn_kmer_hash128(packed, p, k) : dcn_kmer_hash64(packed, p, k);
+            if (act) {
+                uint32_t msh = (uint32_t)(p & 31);
+                uint64_t mbits = ((uint64_t)__funnelshift_r(mw[1], mw[2], msh) << 32) | __funnelshift_r(mw[0], mw[1], msh);
+                valid = (mbits & ((~0ull) >> (64 - k))) == 0; // src/filter_common.rs:275-286
+                uint32_t psh = (uint32_t)(p & 15) * 2;
+                uint64_t lo64 = ((uint64_t)__funnelshift_r(pw[1], pw[2], psh) << 32) | __funnelshift_r(pw[0], pw[1], psh);
+                if constexpr (K128) {
+                    uint64_t hi64 = ((uint64_t)__funnelshift_r(pw[3], pw[NPW - 1], psh) << 32) | __funnelshift_r(pw[2], pw[3], psh);
+                    hash = dcn_kmer_hash128_bits(lo64, hi64, k);
+                } else {
+                    hash = dcn_kmer_hash64_bits(lo64, k);
+                }
+            }
             if (DUMP) {
                 uint32_t o_eb = __shfl(emitted_before, owner, 64);
                 uint32_t o_rp = __shfl(t.read_pos, owner, 64);
                 uint32_t o_carry = __shfl(carry, owner, 64);
                 if (act) {
                     uint64_t slot = (uint64_t)o_s + o_carry + o_eb + idx;
-                    a.dump_hash[slot] = hash;
+                    a.dump_hash[slot] = valid ? hash : 0;
                     a.dump_pos[slot] = o_rp + rel;
                     a.dump_valid[slot] = valid ? 1 : 0;
                 }
-            } else {
-                if (valid) atomicAdd(&sh.total[o_uslot], 1u);
-                bool hit = valid && dcn_table_contains_dev(a.table, hash);
-                unsigned long long hb = __ballot(hit);
+                continue;
+            }
+            // set membership: one 32-byte group, walking on only when the group is full without the key
+            bool hit = false;
+            if (valid) {
+                if (DCN_EXP & 1) {
+                    hit = (hash & 1) != 0;
+                } else if (hash == 0) {
+                    hit = a.table.has_zero != 0;
+                } else {
+                    uint32_t grp = dcn_group_of(hash, a.table.group_shift, a.table.group_mask);
+                    int r = dcn_group_resolve(dcn_load_group(a.table, grp), hash);
+                    while (r < 0) {
+                        grp = (grp + 1) & a.table.group_mask;
+                        r = dcn_group_resolve(dcn_load_group(a.table, grp), hash);
+                    }
+                    hit = r == 1;
+                }
+            } else if (act) {
+                atomicSub(&sh.total[o_uslot], 1u); // rare: k-mer with a non-ACGT base
+            }
+            const bool lok = hit && sh.lok[o_uslot];
+            // hits of units resolved in-wave: through the ring, compared with the unit's earlier hits
+            {
+                unsigned long long hb = __ballot(lok);
                 uint32_t nh = (uint32_t)__popcll(hb);
-                if (n_hits + nh > DCN_HCAP) { // wave-uniform
-                    go_global = true;
-                    spill_hits();
+                uint32_t x = n_ring + (uint32_t)__popcll(hb & ((1ull << lane) - 1));
+                if (lok) {
+                    sh.ring_hash[x & (DCN_RCAP - 1)] = hash;
+                    sh.ring_unit[x & (DCN_RCAP - 1)] = (uint8_t)o_uslot;
                 }
-                if (hit) {
-                    uint32_t x = n_hits + (uint32_t)__popcll(hb & ((1ull << lane) - 1));
-                    sh.hit_hash[x] = hash;
-                    sh.hit_unit[x] = (uint8_t)o_uslot;
+                n_ring += nh;
+                __syncthreads();
+                if (lok) {
+                    bool dup = false;
+                    for (uint32_t d = 1; d <= x; ++d) {
+                        uint32_t y = x - d;
+                        if (y + DCN_RCAP < n_ring) break; // older than the ring (never the case for a resolved unit)
+                        if (sh.ring_unit[y & (DCN_RCAP - 1)] != (uint8_t)o_uslot) break;
+                        if (sh.ring_hash[y & (DCN_RCAP - 1)] == hash) {
+                            dup = true;
+                            break;
+                        }
+                    }
+                    if (!dup) atomicAdd(&sh.hits[o_uslot], 1u);
                 }
-                n_hits += nh;
+                __syncthreads();
+            }
+            // hits of every other unit: exported as (unit, hash) records
+            {
+                const bool rec = hit && !lok;
+                unsigned long long rb = __ballot(rec);
+                if (rb) { // wave-uniform
+                    uint32_t nrec = (uint32_t)__popcll(rb);
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(&a.status->rec_count, (unsigned long long)nrec);
+                    base = __shfl(base, 0, 64);
+                    if (rec) {
+                        unsigned long long ridx = base + (uint32_t)__popcll(rb & ((1ull << lane) - 1));
+                        if (ridx < a.rec_capacity) {
+                            uint32_t gu = sh.unit_of[o_uslot];
+                            a.rec_unit[ridx] = gu;
+                            a.rec_hash[ridx] = hash;
+                            atomicAdd(&a.g_hitcnt[gu], 1u);
+                        } else {
+                            a.status->rec_overflow = 1;
+                        }
+                    }
+                }
             }
         }
-        emitted_before += cnt;
+        if (!DUMP && cnt_eff) atomicAdd(&sh.total[uslot], cnt_eff); // invalid ones were subtracted above
+        emitted_before += cnt_eff;
+        if (skip0) first_pending = false;
         cnt = 0;
         __syncthreads();
-        if (!DUMP && go_global) spill_hits();
     };
 
-    // ---- phase A: rolling scan ---------------------------------------------------------------------------
-    uint32_t ringL[W > 0 ? W : 1], ringR[W > 0 ? W : 1];
+    // ---- phase A: rolling scan in blocks of STEP bases ---------------------------------------------------------
+    // Block b covers main steps t = (k-1) + STEP*b + r.  Each of the three base streams (incoming base t,
+    // k-mer's first base t-(k-1), window's first base t-(l-1)) is read as one 32-bit word per block holding the
+    // block's 2*STEP bits at static offsets 2r; the raw words of block b+1 are loaded while block b computes.
+    constexpr uint32_t STEP = W > 0 ? (uint32_t)W : 8u; // steps between flush checks (= ring size for W > 0)
+    static_assert(STEP < DCN_LCAP && STEP <= 16, "a block's bits must fit one word and the list must outlast a block");
+    uint32_t ringL[STEP], ringR[STEP];
     uint32_t pl = 0xFFFFFFFFu, pr = 0;
     if (W > 0) {
 #pragma unroll
-        for (int r = 0; r < (W > 0 ? W : 1); ++r) {
+        for (uint32_t r = 0; r < STEP; ++r) {
             ringL[r] = 0xFFFFFFFFu;
             ringR[r] = 0;
         }
     } else {
         for (uint32_t r = 0; r < w; ++r) dyn_ring[r * DCN_WAVE + lane] = make_uint2(0xFFFFFFFFu, 0u);
     }
-    uint32_t w_in = 0, w_k = 0, w_l = 0;
-    {
-        uint32_t c0 = (k - 1) >> 4;
-        w_in = __funnelshift_r(packed[q_in + c0], packed[q_in + c0 + 1], sh_in);
-        w_k = __funnelshift_r(packed[q_k + c0], packed[q_k + c0 + 1], sh_k);
-        w_l = __funnelshift_r(packed[q_l + c0], packed[q_l + c0 + 1], sh_l);
-    }
-    constexpr uint32_t STEP = W > 0 ? (uint32_t)W : 8u; // steps between flush checks (= ring size for W > 0)
-    static_assert(STEP < DCN_LCAP, "list capacity must exceed one step block");
     uint32_t gslot = 0; // W == 0: runtime ring slot, j % w
+    uint32_t keymask = 0xFFFF0000u;
+    asm volatile("" : "+v"(keymask)); // keep the mask in a VGPR so (h & mask) | j is one v_bfi_b32
+    const uint32_t lhalf = l >> 1;    // window is canonical iff tg > l/2 (l odd)
 
-    for (uint32_t jb = 0; jb < jmax; jb += STEP) {
+    // bit positions (in the packed stream) of block 0 of the three streams
+    int64_t b_in = 2 * (s + (int64_t)(k - 1)), b_k = 2 * s, b_l = 2 * (s - (int64_t)(w - 1));
+    int64_t wi_in = b_in >> 5, wi_k = b_k >> 5, wi_l = b_l >> 5;
+    uint32_t so_in = (uint32_t)(b_in & 31), so_k = (uint32_t)(b_k & 31), so_l = (uint32_t)(b_l & 31);
+    uint32_t ra_in = packed[wi_in], rb_in = packed[wi_in + 1];
+    uint32_t ra_k = packed[wi_k], rb_k = packed[wi_k + 1];
+    uint32_t ra_l = packed[wi_l], rb_l = packed[wi_l + 1];
+    uint32_t w_in = __funnelshift_r(ra_in, rb_in, so_in);
+    uint32_t w_k = __funnelshift_r(ra_k, rb_k, so_k);
+    uint32_t w_l = __funnelshift_r(ra_l, rb_l, so_l);
+    auto advance_streams = [&]() {
+        so_in += 2 * STEP; wi_in += so_in >> 5; so_in &= 31;
+        so_k += 2 * STEP; wi_k += so_k >> 5; so_k &= 31;
+        so_l += 2 * STEP; wi_l += so_l >> 5; so_l &= 31;
+        ra_in = packed[wi_in]; rb_in = packed[wi_in + 1];
+        ra_k = packed[wi_k]; rb_k = packed[wi_k + 1];
+        ra_l = packed[wi_l]; rb_l = packed[wi_l + 1];
+    };
+    advance_streams(); // raw words of block 1 in flight
+    {
+        // the main loop subtracts the TG bit of base t-(l-1) from its first step on; for t < l-1 that is one of
+        // the w-1 bases in front of the tile: pre-add them so the subtraction cancels.
+        if (W > 0) {
+            uint32_t m = (w - 1) >= 16 ? 0xAAAAAAAAu : (0xAAAAAAAAu & ((1u << (2 * (w - 1))) - 1u));
+            tg += __popc(w_l & m); // w_l of block 0 starts at base s-(w-1)
+        } else {
+            for (uint32_t b = 1; b < w; ++b) {
+                int64_t p = s - (int64_t)b;
+                tg += (packed[p >> 4] >> (2 * (uint32_t)(p & 15) + 1)) & 1u;
+            }
+        }
+    }
+    uint4 e_nx = sh.tab[(w_in & 3) | ((w_k & 3) << 2)]; // table entry of the block's first step, one step ahead
+
+    // one block of STEP steps; FIRST: the tile's first block (for W > 0 exactly one window completes, at its end)
+    auto block = [&](auto first_tag, const uint32_t jb) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        // nibble n of te / to = (k-code << 2 | in-code) of step 2n / 2n+1
+        const uint32_t te = (w_in & 0x33333333u) | ((w_k & 0x33333333u) << 2);
+        const uint32_t to = ((w_in >> 2) & 0x33333333u) | (w_k & 0xCCCCCCCCu);
+        uint32_t nw_in = 0, nw_k = 0, nw_l = 0;
 #pragma unroll
         for (uint32_t r = 0; r < STEP; ++r) {
-            const uint32_t j = jb + r;     // k-mer index within the tile scan (wave-uniform)
-            const uint32_t tt = j + k - 1; // base index within the tile scan (wave-uniform)
-            const uint32_t ti = tt & 15;
-            if (ti == 0) {
-                uint32_t c = tt >> 4;
-                w_in = __funnelshift_r(packed[q_in + c], packed[q_in + c + 1], sh_in);
-                w_k = __funnelshift_r(packed[q_k + c], packed[q_k + c + 1], sh_k);
-                w_l = __funnelshift_r(packed[q_l + c], packed[q_l + c + 1], sh_l);
+            const uint32_t j = jb + r; // k-mer index within the tile scan (wave-uniform)
+            const uint4 e = e_nx;
+            if (r + 1 < STEP) {
+                const uint32_t tsel = ((r + 1) & 1) ? to : te;
+                const uint32_t n = (r + 1) >> 1;
+                const uint32_t addr16 = n == 0 ? ((tsel << 4) & 0xF0u) : ((tsel >> (4 * n - 4)) & 0xF0u);
+                e_nx = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(sh.tab) + addr16);
+            } else {
+                // last step: the next block's words are due; fetch its first table entry and the words after it
+                nw_in = __funnelshift_r(ra_in, rb_in, so_in);
+                nw_k = __funnelshift_r(ra_k, rb_k, so_k);
+                nw_l = __funnelshift_r(ra_l, rb_l, so_l);
+                e_nx = sh.tab[(nw_in & 3) | ((nw_k & 3) << 2)];
+                advance_streams();
             }
-            const uint32_t cin = (w_in >> (2 * ti)) & 3;
-            const uint32_t ck = (w_k >> (2 * ti)) & 3;
-            const uint32_t hl = (w_l >> (2 * ti + 1)) & 1;
-            const uint4 e = sh.tab[cin | (ck << 2)];
-            const uint32_t fwo = rotl32(fw, 1) ^ e.x;
-            const uint32_t rco = rotl32(rc, 31) ^ e.y;
-            const uint32_t h = fwo + rco;
-            fw = fwo ^ e.z;
-            rc = rco ^ e.w;
-            const uint32_t lk = (h & 0xFFFF0000u) | j;
+            const uint32_t hi_in = (w_in >> (2 * r + 1)) & 1;
+            const uint32_t hl = (w_l >> (2 * r + 1)) & 1;
+            fw = rotl32(fw, 1) ^ zprev ^ e.x;
+            rc = rotl32(rc, 31) ^ wprev ^ e.y;
+            zprev = e.z;
+            wprev = e.w;
+            const uint32_t h = fw + rc;
+            const uint32_t lk = (h & keymask) | (j & ~keymask);
             const uint32_t rk = lk ^ 0xFFFF0000u;
             uint32_t lmin, rmax;
             if constexpr (W > 0) {
@@ -310,18 +430,40 @@ __global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
                     rmax = max(rmax, v.y);
                 }
             }
-            tg += cin >> 1;
-            const bool canonical = 2 * tg > l;
-            const uint32_t sel = (canonical ? lmin : rmax) & 0xFFFFu;
+            tg += hi_in;
+            if constexpr (W > 0) {
+                if (!FIRST || r == STEP - 1) {
+                    const uint32_t sel = ((tg > lhalf) ? lmin : rmax) & 0xFFFFu;
+                    // FIRST: window 0, always emitted (a carry tile's copy is dropped in phase B);
+                    // later blocks: window j-(w-1) >= 1, emitted when in range and different from its predecessor
+                    const bool emit = FIRST ? (nwc > 0) : ((j - (w - 1) < nwc) && sel != prev);
+                    if (!(DCN_EXP & 4)) sh.list[cnt][lane] = (uint16_t)sel;
+                    cnt += emit ? 1u : 0u;
+                    prev = sel;
+                }
+            } else {
+                const uint32_t sel = ((tg > lhalf) ? lmin : rmax) & 0xFFFFu;
+                const uint32_t i = j - (w - 1); // window index; wraps while j < w-1
+                const bool in_range = i < nwc;  // unsigned compare: false while i is "negative"
+                const bool emit = in_range && sel != prev;
+                sh.list[cnt][lane] = (uint16_t)sel;
+                cnt += emit ? 1u : 0u;
+                prev = in_range ? sel : prev;
+            }
             tg -= hl;
-            const uint32_t i = j - (w - 1); // window index within the tile scan; wraps while j < w-1
-            const bool in_range = i < nwc;  // unsigned compare: false while i is "negative"
-            const bool emit = in_range && sel != prev && !(carry && i == 0);
-            sh.list[cnt][lane] = (uint16_t)sel;
-            cnt += emit ? 1u : 0u;
-            prev = in_range ? sel : prev;
         }
+        w_in = nw_in;
+        w_k = nw_k;
+        w_l = nw_l;
+    };
+
+    if (jmax > 0) {
+        block(BoolTag<true>{}, 0);
         if (__any(cnt > DCN_LCAP - STEP)) flush(false);
+        for (uint32_t jb = STEP; jb < jmax; jb += STEP) {
+            block(BoolTag<false>{}, jb);
+            if (__any(cnt > DCN_LCAP - STEP)) flush(false);
+        }
     }
     flush(true);
     if (DUMP) {
@@ -329,48 +471,10 @@ __global__ __launch_bounds__(DCN_WAVE) void scan_kernel(dcn_scan_args a) {
         return;
     }
 
-    // ---- finish the units this wave owns -------------------------------------------------------------------
-    if (!go_global) {
-        unsigned long long base = 0;
-        for (uint32_t x0 = 0; x0 < n_hits; x0 += DCN_WAVE) {
-            uint32_t x = x0 + lane;
-            bool act = x < n_hits;
-            uint32_t u = act ? sh.hit_unit[x] : 0;
-            bool loc = act && sh.local[u];
-            if (loc) {
-                uint64_t hv = sh.hit_hash[x];
-                bool dup = false;
-                for (int y = (int)x - 1; y >= 0 && sh.hit_unit[y] == u; --y)
-                    if (sh.hit_hash[y] == hv) {
-                        dup = true;
-                        break;
-                    }
-                if (!dup) atomicAdd(&sh.hits[u], 1u);
-            }
-            bool rec = act && !loc;
-            unsigned long long rb = __ballot(rec);
-            if (rb) { // wave-uniform
-                uint32_t nrec = (uint32_t)__popcll(rb);
-                if (lane == 0) base = atomicAdd(&a.status->rec_count, (unsigned long long)nrec);
-                base = __shfl(base, 0, 64);
-                if (rec) {
-                    unsigned long long ridx = base + (uint32_t)__popcll(rb & ((1ull << lane) - 1));
-                    if (ridx < a.rec_capacity) {
-                        uint32_t gu = sh.unit_of[u];
-                        a.rec_unit[ridx] = gu;
-                        a.rec_hash[ridx] = sh.hit_hash[x];
-                        atomicAdd(&a.g_hitcnt[gu], 1u);
-                    } else {
-                        a.status->rec_overflow = 1;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
+    // ---- results of the units this wave owns --------------------------------------------------------------
     if (head && have_tile) {
         uint32_t tot = sh.total[uslot];
-        if (!go_global && sh.local[uslot]) {
+        if (sh.lok[uslot]) {
             uint32_t hc = sh.hits[uslot];
             a.keep[t.unit] = dcn_decide(hc, tot, a.abs_threshold, a.rel_threshold, a.deplete) ? 1 : 0;
             if (a.hits) a.hits[t.unit] = hc;

@@ -83,6 +83,10 @@ class Index:
         N.check(N.lib().dcn_index_contains(self._h, _ptr(keys), len(keys), _ptr(out)))
         return out.astype(bool)
 
+    def contains_device(self, d_keys, n, d_out, stream=None):
+        """Device-resident probe: d_keys / d_out are raw device pointers; asynchronous on `stream`."""
+        N.check(N.lib().dcn_index_contains_device(self._h, d_keys, n, d_out, stream))
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib().dcn_index_destroy(self._h)

@@ -84,6 +84,11 @@ int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n
 /* Set membership for `n` host keys -> out[i] in {0,1}: FxHashSet::contains (src/filter_common.rs:144). */
 int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n, uint8_t *out);
 
+/* Same for keys already in device memory (d_keys, d_out are DEVICE pointers on the index's GPU); enqueued on
+ * `stream` (a hipStream_t, NULL = default stream) without waiting. */
+int dcn_index_contains_device(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
+                              void *stream);
+
 void dcn_index_destroy(dcn_index *index);
 
 /* ---- context -------------------------------------------------------------------------------------- */

@@ -1,0 +1,16 @@
+#!/bin/bash
+# time the scan stage for each experiment variant: profiles/run_variants.sh "<bench args>" name1 name2 ...
+ARGS=$1; shift
+for v in "$@"; do
+  if [ "$v" = base ]; then lib=""; else lib="$GRAFT_REPO_ROOT/deacon-server_amd/lib/variants/libdeacon_hip_$v.so"; fi
+  DCN_LIB_PATH=$lib timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline > gpurun_out/var_$v.json 2> gpurun_out/var_$v.err || echo "$v FAILED"
+  python - "$v" <<'PY'
+import json,sys
+v=sys.argv[1]
+try:
+    d=json.load(open(f"gpurun_out/var_{v}.json"))
+    print(f"{v:18s} value={d['value']:.0f} ms/step={d['ms_per_step']:.3f} scan={d['stage_ms_per_step']['scan']:.3f} kept={d['kept_fraction']:.4f}")
+except Exception as e:
+    print(v, "no result", e)
+PY
+done

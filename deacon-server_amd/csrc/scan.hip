@@ -55,10 +55,10 @@ struct WaveShared {
     uint4 tab[16];                      // {F[in], rotl(F[in^2],k-1), rotl(F[out],k), rotr(F[out^2],1)} at in | out<<2
     uint16_t list[DCN_LCAP][DCN_WAVE];  // per-lane emitted positions (relative to the tile's scan start)
     uint64_t ring_hash[DCN_RCAP];
-    uint8_t ring_unit[DCN_RCAP];
     uint32_t total[DCN_WAVE];           // per unit slot: emitted minimizers minus those failing the ACGT test
     uint32_t hits[DCN_WAVE];            // per unit slot: distinct hits
     uint32_t items[DCN_WAVE];           // per unit slot: emitted minimizers (bounds the ring span)
+    uint32_t hraw[DCN_WAVE];            // per unit slot: hits pushed through the ring so far
     uint32_t unit_of[DCN_WAVE];         // unit slot -> global unit id
     uint16_t start[DCN_WAVE + 2];       // exclusive prefix of the per-lane list lengths
     uint8_t local[DCN_WAVE];            // unit slot has all its tiles in this wave
@@ -66,7 +66,8 @@ struct WaveShared {
 };
 
 #ifndef DCN_EXP
-#define DCN_EXP 0 // experiment bits (timing-only builds): 1 = no set probe, 2 = no phase B, 4 = no list store
+#define DCN_EXP 0 // experiment bits (timing-only builds, results wrong): 1 = no set probe, 2 = no phase B,
+                  // 4 = no list store, 8 = no duplicate compare, 16 = no mask loads
 #endif
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
     sh.total[lane] = 0;
     sh.hits[lane] = 0;
     sh.items[lane] = 0;
+    sh.hraw[lane] = 0;
     sh.lok[lane] = 0;
     if (head) {
         sh.unit_of[uslot] = t.unit;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                 const uint32_t *mp = a.invmask + (p >> 5);
                 const uint32_t *pp = packed + (p >> 4);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) mw[q] = mp[q];
+                for (int q = 0; q < 3; ++q) mw[q] = (DCN_EXP & 16) ? 0u : mp[q];
 #pragma unroll
                 for (int q = 0; q < NPW; ++q) pw[q] = pp[q];
             }
@@ -252,30 +254,39 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                 atomicSub(&sh.total[o_uslot], 1u); // rare: k-mer with a non-ACGT base
             }
             const bool lok = hit && sh.lok[o_uslot];
-            // hits of units resolved in-wave: through the ring, compared with the unit's earlier hits
+            // hits of units resolved in-wave: through the ring, compared with the unit's earlier hits.  Items are
+            // in flat order, so a unit's hits occupy consecutive ring slots: a hit with `run` earlier hits of its
+            // unit (earlier rounds: sh.hraw, this round: ballot arithmetic) compares with the `run` slots before it.
             {
-                unsigned long long hb = __ballot(lok);
-                uint32_t nh = (uint32_t)__popcll(hb);
-                uint32_t x = n_ring + (uint32_t)__popcll(hb & ((1ull << lane) - 1));
-                if (lok) {
-                    sh.ring_hash[x & (DCN_RCAP - 1)] = hash;
-                    sh.ring_unit[x & (DCN_RCAP - 1)] = (uint8_t)o_uslot;
-                }
-                n_ring += nh;
+                const unsigned long long lt = (1ull << lane) - 1;
+                const unsigned long long hb = __ballot(lok);
+                const uint32_t nh = (uint32_t)__popcll(hb);
+                const uint32_t rank = (uint32_t)__popcll(hb & lt);
+                const uint32_t x = n_ring + rank;
+                if (lok) sh.ring_hash[x & (DCN_RCAP - 1)] = hash;
+                const unsigned long long below = hb & lt;
+                const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
+                const uint32_t prev_us = __shfl(o_uslot, prev_lane, 64);
+                const bool run_head = lok && (below == 0 || prev_us != o_uslot);
+                const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
+                const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
+                const uint32_t rank_head = (uint32_t)__popcll(hb & ((1ull << head_lane) - 1));
+                const uint32_t run = lok ? sh.hraw[o_uslot] + (rank - rank_head) : 0u;
                 __syncthreads();
+                bool dup = false;
+                for (uint32_t d0 = 0; __any(d0 < ((DCN_EXP & 8) ? 0u : run)); d0 += 4) {
+                    uint64_t v0 = sh.ring_hash[(x - d0 - 1) & (DCN_RCAP - 1)];
+                    uint64_t v1 = sh.ring_hash[(x - d0 - 2) & (DCN_RCAP - 1)];
+                    uint64_t v2 = sh.ring_hash[(x - d0 - 3) & (DCN_RCAP - 1)];
+                    uint64_t v3 = sh.ring_hash[(x - d0 - 4) & (DCN_RCAP - 1)];
+                    dup |= (d0 + 0 < run && v0 == hash) | (d0 + 1 < run && v1 == hash) |
+                           (d0 + 2 < run && v2 == hash) | (d0 + 3 < run && v3 == hash);
+                }
                 if (lok) {
-                    bool dup = false;
-                    for (uint32_t d = 1; d <= x; ++d) {
-                        uint32_t y = x - d;
-                        if (y + DCN_RCAP < n_ring) break; // older than the ring (never the case for a resolved unit)
-                        if (sh.ring_unit[y & (DCN_RCAP - 1)] != (uint8_t)o_uslot) break;
-                        if (sh.ring_hash[y & (DCN_RCAP - 1)] == hash) {
-                            dup = true;
-                            break;
-                        }
-                    }
+                    atomicAdd(&sh.hraw[o_uslot], 1u);
                     if (!dup) atomicAdd(&sh.hits[o_uslot], 1u);
                 }
+                n_ring += nh;
                 __syncthreads();
             }
             // hits of every other unit: exported as (unit, hash) records

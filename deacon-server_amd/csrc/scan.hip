@@ -67,7 +67,9 @@ struct WaveShared {
 
 #ifndef DCN_EXP
 #define DCN_EXP 0 // experiment bits (timing-only builds, results wrong): 1 = no set probe, 2 = no phase B,
-                  // 4 = no list store, 8 = no duplicate compare, 16 = no mask loads
+                  // 4 = no list store, 8 = no duplicate compare, 16 = no mask loads,
+                  // 64 = k / l streams reuse the in-stream words (2 instead of 6 stream loads per block),
+                  // 128 = no stream loads at all in the main loop (words recycled)
 #endif
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
@@ -77,6 +79,13 @@ template <bool B>
 struct BoolTag {
     static constexpr bool value = B;
 };
+template <int N>
+struct IntTag {
+    static constexpr int value = N;
+};
+#ifndef DCN_U_FINAL
+#define DCN_U_FINAL 2 // items per lane per phase-B group in the final flush (1..4 measure the same)
+#endif
 
 // W > 0: window size known at compile time, ring in registers.  W == 0: runtime w, ring in dynamic LDS.
 template <int W, bool K128, bool DUMP>
@@ -160,9 +169,12 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
     const uint32_t nk = nwc ? nwc + w - 1 : 0;
     const uint32_t jmax = wave_max_u32(nk);
 
-    // Phase B.  Flattens the 64 lists (item e belongs to the lane whose prefix range holds e); one item per lane
-    // and round.
-    auto flush = [&](bool final_flush) {
+    // Phase B.  Flattens the 64 lists (item e belongs to the lane whose prefix range holds e).  A group is U items
+    // per lane (item E + u*64 + lane): the sequence/mask words of the whole group are loaded together, then the
+    // U set groups, so a lane pays one L2 and one HBM latency per U items.  U is a compile-time tag: the final
+    // flush (scan registers dead) uses DCN_U_FINAL, a mid-scan flush 1.
+    auto flush = [&](auto u_tag, bool final_flush) {
+        constexpr int U = decltype(u_tag)::value;
         const uint32_t skip0 = (first_pending && cnt > 0) ? 1u : 0u;
         const uint32_t cnt_eff = cnt - skip0;
         uint32_t incl = wave_inclusive_scan_u32(cnt_eff, lane);
@@ -179,134 +191,178 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
         }
         __syncthreads();
         constexpr int NPW = K128 ? 5 : 3; // packed words per k-mer
-        for (uint32_t E = 0; E < ((DCN_EXP & 2) ? 0u : M); E += DCN_WAVE) {
-            const uint32_t e = E + lane;
-            const bool act = e < M;
-            // owner = largest lane whose list starts at or before e
-            uint32_t lo = 0, hi = 63;
+        for (uint32_t E = 0; E < ((DCN_EXP & 2) ? 0u : M); E += DCN_WAVE * U) {
+            bool act[U];
+            uint32_t lo[U], hi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                act[u] = E + u * DCN_WAVE + lane < M;
+                lo[u] = 0;
+                hi[u] = 63;
+            }
+            // owner = largest lane whose list starts at or before e (6 steps, the U searches interleaved)
 #pragma unroll
             for (int it = 0; it < 6; ++it) {
-                uint32_t mid = (lo + hi + 1) >> 1;
-                bool le = sh.start[mid] <= e;
-                lo = le ? mid : lo;
-                hi = le ? hi : mid - 1;
-            }
-            const uint32_t owner = lo;
-            const uint32_t idx = act ? e - sh.start[owner] : 0;
-            const uint32_t o_skip = __shfl(skip0, owner, 64);
-            const uint32_t rel = sh.list[idx + o_skip][owner];
-            const long long o_s = __shfl((long long)s, owner, 64);
-            const uint32_t o_uslot = __shfl(uslot, owner, 64);
-            const uint64_t p = (uint64_t)(o_s + rel);
-            uint32_t mw[3], pw[NPW];
-            if (act) {
-                const uint32_t *mp = a.invmask + (p >> 5);
-                const uint32_t *pp = packed + (p >> 4);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) mw[q] = (DCN_EXP & 16) ? 0u : mp[q];
-#pragma unroll
-                for (int q = 0; q < NPW; ++q) pw[q] = pp[q];
+                for (int u = 0; u < U; ++u) {
+                    uint32_t e = E + u * DCN_WAVE + lane;
+                    uint32_t mid = (lo[u] + hi[u] + 1) >> 1;
+                    bool le = sh.start[mid] <= e;
+                    lo[u] = le ? mid : lo[u];
+                    hi[u] = le ? hi[u] : mid - 1;
+                }
             }
-            bool valid = false;
-            uint64_t hash = 0;
-            if (act) {
-                uint32_t msh = (uint32_t)(p & 31);
-                uint64_t mbits = ((uint64_t)__funnelshift_r(mw[1], mw[2], msh) << 32) | __funnelshift_r(mw[0], mw[1], msh);
-                valid = (mbits & ((~0ull) >> (64 - k))) == 0; // src/filter_common.rs:275-286
-                uint32_t psh = (uint32_t)(p & 15) * 2;
-                uint64_t lo64 = ((uint64_t)__funnelshift_r(pw[1], pw[2], psh) << 32) | __funnelshift_r(pw[0], pw[1], psh);
-                if constexpr (K128) {
-                    uint64_t hi64 = ((uint64_t)__funnelshift_r(pw[3], pw[NPW - 1], psh) << 32) | __funnelshift_r(pw[2], pw[3], psh);
-                    hash = dcn_kmer_hash128_bits(lo64, hi64, k);
-                } else {
-                    hash = dcn_kmer_hash64_bits(lo64, k);
+            uint64_t p[U];
+            uint32_t o_uslot[U], idx[U], rel[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t e = E + u * DCN_WAVE + lane;
+                idx[u] = act[u] ? e - sh.start[lo[u]] : 0;
+                uint32_t o_skip = __shfl(skip0, lo[u], 64);
+                rel[u] = sh.list[idx[u] + o_skip][lo[u]];
+                long long o_s = __shfl((long long)s, lo[u], 64);
+                o_uslot[u] = __shfl(uslot, lo[u], 64);
+                p[u] = (uint64_t)(o_s + rel[u]);
+            }
+            uint32_t mw[U][3], pw[U][NPW];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (act[u]) {
+                    const uint32_t *mp = a.invmask + (p[u] >> 5);
+                    const uint32_t *pp = packed + (p[u] >> 4);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) mw[u][q] = (DCN_EXP & 16) ? 0u : mp[q];
+#pragma unroll
+                    for (int q = 0; q < NPW; ++q) pw[u][q] = pp[q];
+                }
+            }
+            bool valid[U];
+            uint64_t hash[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                valid[u] = false;
+                hash[u] = 0;
+                if (act[u]) {
+                    uint32_t msh = (uint32_t)(p[u] & 31);
+                    uint64_t mbits = ((uint64_t)__funnelshift_r(mw[u][1], mw[u][2], msh) << 32) |
+                                     __funnelshift_r(mw[u][0], mw[u][1], msh);
+                    valid[u] = (mbits & ((~0ull) >> (64 - k))) == 0; // src/filter_common.rs:275-286
+                    uint32_t psh = (uint32_t)(p[u] & 15) * 2;
+                    uint64_t lo64 = ((uint64_t)__funnelshift_r(pw[u][1], pw[u][2], psh) << 32) |
+                                    __funnelshift_r(pw[u][0], pw[u][1], psh);
+                    if constexpr (K128) {
+                        uint64_t hi64 = ((uint64_t)__funnelshift_r(pw[u][3], pw[u][NPW - 1], psh) << 32) |
+                                        __funnelshift_r(pw[u][2], pw[u][3], psh);
+                        hash[u] = dcn_kmer_hash128_bits(lo64, hi64, k);
+                    } else {
+                        hash[u] = dcn_kmer_hash64_bits(lo64, k);
+                    }
                 }
             }
             if (DUMP) {
-                uint32_t o_eb = __shfl(emitted_before, owner, 64);
-                uint32_t o_rp = __shfl(t.read_pos, owner, 64);
-                uint32_t o_carry = __shfl(carry, owner, 64);
-                if (act) {
-                    uint64_t slot = (uint64_t)o_s + o_carry + o_eb + idx;
-                    a.dump_hash[slot] = valid ? hash : 0;
-                    a.dump_pos[slot] = o_rp + rel;
-                    a.dump_valid[slot] = valid ? 1 : 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint32_t o_eb = __shfl(emitted_before, lo[u], 64);
+                    uint32_t o_rp = __shfl(t.read_pos, lo[u], 64);
+                    uint32_t o_carry = __shfl(carry, lo[u], 64);
+                    long long o_s = __shfl((long long)s, lo[u], 64);
+                    if (act[u]) {
+                        uint64_t slot = (uint64_t)o_s + o_carry + o_eb + idx[u];
+                        a.dump_hash[slot] = valid[u] ? hash[u] : 0;
+                        a.dump_pos[slot] = o_rp + rel[u];
+                        a.dump_valid[slot] = valid[u] ? 1 : 0;
+                    }
                 }
                 continue;
             }
-            // set membership: one 32-byte group, walking on only when the group is full without the key
-            bool hit = false;
-            if (valid) {
-                if (DCN_EXP & 1) {
-                    hit = (hash & 1) != 0;
-                } else if (hash == 0) {
-                    hit = a.table.has_zero != 0;
-                } else {
-                    uint32_t grp = dcn_group_of(hash, a.table.group_shift, a.table.group_mask);
-                    int r = dcn_group_resolve(dcn_load_group(a.table, grp), hash);
-                    while (r < 0) {
-                        grp = (grp + 1) & a.table.group_mask;
-                        r = dcn_group_resolve(dcn_load_group(a.table, grp), hash);
+            // set membership: one 32-byte group per item, the U loads in flight together; walking on to the next
+            // group only when a group is full without the key (rare at load <= 0.5)
+            uint32_t grp[U];
+            dcn_group g[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                grp[u] = dcn_group_of(hash[u], a.table.group_shift, a.table.group_mask);
+                if (valid[u] && !(DCN_EXP & 1)) g[u] = dcn_load_group(a.table, grp[u]);
+            }
+            bool hit[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                hit[u] = false;
+                if (valid[u]) {
+                    if (DCN_EXP & 1) {
+                        hit[u] = (hash[u] & 1) != 0;
+                    } else if (hash[u] == 0) {
+                        hit[u] = a.table.has_zero != 0;
+                    } else {
+                        int r = dcn_group_resolve(g[u], hash[u]);
+                        while (r < 0) {
+                            grp[u] = (grp[u] + 1) & a.table.group_mask;
+                            r = dcn_group_resolve(dcn_load_group(a.table, grp[u]), hash[u]);
+                        }
+                        hit[u] = r == 1;
                     }
-                    hit = r == 1;
+                } else if (act[u]) {
+                    atomicSub(&sh.total[o_uslot[u]], 1u); // rare: k-mer with a non-ACGT base
                 }
-            } else if (act) {
-                atomicSub(&sh.total[o_uslot], 1u); // rare: k-mer with a non-ACGT base
             }
-            const bool lok = hit && sh.lok[o_uslot];
-            // hits of units resolved in-wave: through the ring, compared with the unit's earlier hits.  Items are
-            // in flat order, so a unit's hits occupy consecutive ring slots: a hit with `run` earlier hits of its
-            // unit (earlier rounds: sh.hraw, this round: ballot arithmetic) compares with the `run` slots before it.
-            {
-                const unsigned long long lt = (1ull << lane) - 1;
-                const unsigned long long hb = __ballot(lok);
-                const uint32_t nh = (uint32_t)__popcll(hb);
-                const uint32_t rank = (uint32_t)__popcll(hb & lt);
-                const uint32_t x = n_ring + rank;
-                if (lok) sh.ring_hash[x & (DCN_RCAP - 1)] = hash;
-                const unsigned long long below = hb & lt;
-                const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
-                const uint32_t prev_us = __shfl(o_uslot, prev_lane, 64);
-                const bool run_head = lok && (below == 0 || prev_us != o_uslot);
-                const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
-                const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
-                const uint32_t rank_head = (uint32_t)__popcll(hb & ((1ull << head_lane) - 1));
-                const uint32_t run = lok ? sh.hraw[o_uslot] + (rank - rank_head) : 0u;
-                __syncthreads();
-                bool dup = false;
-                for (uint32_t d0 = 0; __any(d0 < ((DCN_EXP & 8) ? 0u : run)); d0 += 4) {
-                    uint64_t v0 = sh.ring_hash[(x - d0 - 1) & (DCN_RCAP - 1)];
-                    uint64_t v1 = sh.ring_hash[(x - d0 - 2) & (DCN_RCAP - 1)];
-                    uint64_t v2 = sh.ring_hash[(x - d0 - 3) & (DCN_RCAP - 1)];
-                    uint64_t v3 = sh.ring_hash[(x - d0 - 4) & (DCN_RCAP - 1)];
-                    dup |= (d0 + 0 < run && v0 == hash) | (d0 + 1 < run && v1 == hash) |
-                           (d0 + 2 < run && v2 == hash) | (d0 + 3 < run && v3 == hash);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool lok = hit[u] && sh.lok[o_uslot[u]];
+                // hits of units resolved in-wave: through the ring, compared with the unit's earlier hits.  Items
+                // are in flat order, so a unit's hits occupy consecutive ring slots: a hit with `run` earlier hits
+                // of its unit (earlier rounds: sh.hraw, this round: ballot arithmetic) compares with the `run`
+                // slots before it.
+                {
+                    const unsigned long long lt = (1ull << lane) - 1;
+                    const unsigned long long hb = __ballot(lok);
+                    const uint32_t nh = (uint32_t)__popcll(hb);
+                    const uint32_t rank = (uint32_t)__popcll(hb & lt);
+                    const uint32_t x = n_ring + rank;
+                    if (lok) sh.ring_hash[x & (DCN_RCAP - 1)] = hash[u];
+                    const unsigned long long below = hb & lt;
+                    const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
+                    const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
+                    const bool run_head = lok && (below == 0 || prev_us != o_uslot[u]);
+                    const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
+                    const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
+                    const uint32_t rank_head = (uint32_t)__popcll(hb & ((1ull << head_lane) - 1));
+                    const uint32_t run = lok ? sh.hraw[o_uslot[u]] + (rank - rank_head) : 0u;
+                    __syncthreads();
+                    bool dup = false;
+                    for (uint32_t d0 = 0; __any(d0 < ((DCN_EXP & 8) ? 0u : run)); d0 += 4) {
+                        uint64_t v0 = sh.ring_hash[(x - d0 - 1) & (DCN_RCAP - 1)];
+                        uint64_t v1 = sh.ring_hash[(x - d0 - 2) & (DCN_RCAP - 1)];
+                        uint64_t v2 = sh.ring_hash[(x - d0 - 3) & (DCN_RCAP - 1)];
+                        uint64_t v3 = sh.ring_hash[(x - d0 - 4) & (DCN_RCAP - 1)];
+                        dup |= (d0 + 0 < run && v0 == hash[u]) | (d0 + 1 < run && v1 == hash[u]) |
+                               (d0 + 2 < run && v2 == hash[u]) | (d0 + 3 < run && v3 == hash[u]);
+                    }
+                    if (lok) {
+                        atomicAdd(&sh.hraw[o_uslot[u]], 1u);
+                        if (!dup) atomicAdd(&sh.hits[o_uslot[u]], 1u);
+                    }
+                    n_ring += nh;
+                    __syncthreads();
                 }
-                if (lok) {
-                    atomicAdd(&sh.hraw[o_uslot], 1u);
-                    if (!dup) atomicAdd(&sh.hits[o_uslot], 1u);
-                }
-                n_ring += nh;
-                __syncthreads();
-            }
-            // hits of every other unit: exported as (unit, hash) records
-            {
-                const bool rec = hit && !lok;
-                unsigned long long rb = __ballot(rec);
-                if (rb) { // wave-uniform
-                    uint32_t nrec = (uint32_t)__popcll(rb);
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(&a.status->rec_count, (unsigned long long)nrec);
-                    base = __shfl(base, 0, 64);
-                    if (rec) {
-                        unsigned long long ridx = base + (uint32_t)__popcll(rb & ((1ull << lane) - 1));
-                        if (ridx < a.rec_capacity) {
-                            uint32_t gu = sh.unit_of[o_uslot];
-                            a.rec_unit[ridx] = gu;
-                            a.rec_hash[ridx] = hash;
-                            atomicAdd(&a.g_hitcnt[gu], 1u);
-                        } else {
-                            a.status->rec_overflow = 1;
+                // hits of every other unit: exported as (unit, hash) records
+                {
+                    const bool rec = hit[u] && !lok;
+                    unsigned long long rb = __ballot(rec);
+                    if (rb) { // wave-uniform
+                        uint32_t nrec = (uint32_t)__popcll(rb);
+                        unsigned long long base = 0;
+                        if (lane == 0) base = atomicAdd(&a.status->rec_count, (unsigned long long)nrec);
+                        base = __shfl(base, 0, 64);
+                        if (rec) {
+                            unsigned long long ridx = base + (uint32_t)__popcll(rb & ((1ull << lane) - 1));
+                            if (ridx < a.rec_capacity) {
+                                uint32_t gu = sh.unit_of[o_uslot[u]];
+                                a.rec_unit[ridx] = gu;
+                                a.rec_hash[ridx] = hash[u];
+                                atomicAdd(&a.g_hitcnt[gu], 1u);
+                            } else {
+                                a.status->rec_overflow = 1;
+                            }
                         }
                     }
                 }
@@ -355,9 +411,17 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
         so_in += 2 * STEP; wi_in += so_in >> 5; so_in &= 31;
         so_k += 2 * STEP; wi_k += so_k >> 5; so_k &= 31;
         so_l += 2 * STEP; wi_l += so_l >> 5; so_l &= 31;
+        if (DCN_EXP & 128) {
+            ra_in = rb_in ^ 0x5A5A5A5Au; rb_in = ra_k + 0x1234567u; ra_k = rb_l; rb_k = ra_l ^ ra_in; ra_l = rb_k; rb_l = rb_in;
+            return;
+        }
         ra_in = packed[wi_in]; rb_in = packed[wi_in + 1];
-        ra_k = packed[wi_k]; rb_k = packed[wi_k + 1];
-        ra_l = packed[wi_l]; rb_l = packed[wi_l + 1];
+        if (DCN_EXP & 64) {
+            ra_k = ra_in; rb_k = rb_in; ra_l = ra_in; rb_l = rb_in;
+        } else {
+            ra_k = packed[wi_k]; rb_k = packed[wi_k + 1];
+            ra_l = packed[wi_l]; rb_l = packed[wi_l + 1];
+        }
     };
     advance_streams(); // raw words of block 1 in flight
     {
@@ -470,13 +534,13 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
 
     if (jmax > 0) {
         block(BoolTag<true>{}, 0);
-        if (__any(cnt > DCN_LCAP - STEP)) flush(false);
+        if (__any(cnt > DCN_LCAP - STEP)) flush(IntTag<1>{}, false);
         for (uint32_t jb = STEP; jb < jmax; jb += STEP) {
             block(BoolTag<false>{}, jb);
-            if (__any(cnt > DCN_LCAP - STEP)) flush(false);
+            if (__any(cnt > DCN_LCAP - STEP)) flush(IntTag<1>{}, false);
         }
     }
-    flush(true);
+    flush(IntTag<DCN_U_FINAL>{}, true);
     if (DUMP) {
         if (have_tile) a.dump_count[tile_idx] = emitted_before;
         return;

@@ -23,11 +23,20 @@ int dcn_fail(int code, const std::string &msg);
     } while (0)
 
 // ----------------------------------------------------------------------------------------------------
-// device-resident index: open-addressing set, 4-slot (32-byte) groups, linear probing over groups.
-// Slot value 0 = empty; key 0 is tracked by `has_zero`.
+// device-resident index: open-addressing set over groups of DCN_GROUP_SLOTS u64 slots, linear probing group by
+// group.  Slot value 0 = empty; key 0 is tracked by `has_zero`.
+//   DCN_GROUP_SLOTS 2: 16-byte groups, one dwordx4 request per probe, >= 4 slots per key (load <= 0.25)
+//   DCN_GROUP_SLOTS 4: 32-byte groups, two dwordx4 requests per probe, >= 2 slots per key (load <= 0.5)
+// A random probe costs one 64-byte HBM sector either way; what differs is the number of requests the memory
+// pipeline handles per probe (measured: 41 G probes/s with two requests, 47-49 G/s with one).
 // ----------------------------------------------------------------------------------------------------
+#ifndef DCN_GROUP_SLOTS
+#define DCN_GROUP_SLOTS 2
+#endif
+constexpr int DCN_SLOTS_PER_KEY = DCN_GROUP_SLOTS == 2 ? 4 : 2;
+
 struct dcn_table_view {
-    const uint64_t *slots; // n_groups * 4
+    const uint64_t *slots; // n_groups * DCN_GROUP_SLOTS
     uint32_t group_shift;  // 32 - log2(n_groups)
     uint32_t group_mask;   // n_groups - 1
     uint32_t has_zero;

@@ -6,21 +6,31 @@
 
 // ---- set lookup (FxHashSet::contains, src/filter_common.rs:144,185) ---------------------------------
 struct dcn_group {
-    ulonglong2 a, b;
+    ulonglong2 a;
+#if DCN_GROUP_SLOTS == 4
+    ulonglong2 b;
+#endif
 };
 
 __device__ inline dcn_group dcn_load_group(const dcn_table_view &t, uint32_t g) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)g * 4);
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)g * DCN_GROUP_SLOTS);
     dcn_group r;
     r.a = p[0];
+#if DCN_GROUP_SLOTS == 4
     r.b = p[1];
+#endif
     return r;
 }
 
 // 1 = key present in this group, 0 = group has an empty slot (key absent), -1 = walk on
 __device__ inline int dcn_group_resolve(const dcn_group &g, uint64_t key) {
+#if DCN_GROUP_SLOTS == 4
     if (g.a.x == key || g.a.y == key || g.b.x == key || g.b.y == key) return 1;
     if (g.a.x == 0 || g.a.y == 0 || g.b.x == 0 || g.b.y == 0) return 0;
+#else
+    if (g.a.x == key || g.a.y == key) return 1;
+    if (g.a.x == 0 || g.a.y == 0) return 0;
+#endif
     return -1;
 }
 

@@ -2,9 +2,8 @@
 //
 // Replaces the reference's FxHashSet<u64> index (src/index.rs:98-105 insert loop,
 // src/filter_common.rs:144 `contains`).  Only membership is ever observed on the filter path, so the
-// layout is free: open addressing over 32-byte groups of four u64 slots, linear probing group by
-// group, load factor <= 0.5.  One probe = one aligned 32-byte read (two dwordx4), which is what a
-// random access costs in HBM anyway; with <= 50 % load ~93 % of lookups resolve in the first group.
+// layout is free: open addressing over small groups of u64 slots (DCN_GROUP_SLOTS, dcn_internal.h), linear
+// probing group by group.  One probe = one aligned group read inside one 64-byte HBM sector.
 #include "dcn_internal.h"
 #include "dcn_probe.h"
 
@@ -27,8 +26,8 @@ __global__ void table_insert_kernel(uint64_t *slots, uint32_t group_shift, uint3
         uint32_t g = dcn_group_of(key, group_shift, group_mask);
         bool done = false;
         while (!done) {
-            unsigned long long *grp = (unsigned long long *)(slots + (uint64_t)g * 4);
-            for (int s = 0; s < 4 && !done; ++s) {
+            unsigned long long *grp = (unsigned long long *)(slots + (uint64_t)g * DCN_GROUP_SLOTS);
+            for (int s = 0; s < DCN_GROUP_SLOTS && !done; ++s) {
                 unsigned long long cur = __hip_atomic_load(&grp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == key) {
                     done = true;
@@ -58,13 +57,13 @@ __global__ void table_contains_kernel(dcn_table_view t, const uint64_t *keys, ui
 
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n) {
     DCN_HIP(hipSetDevice(idx->device));
-    // capacity: >= 2 slots per key, power-of-two number of 4-slot groups, at least 64 groups
+    // capacity: >= DCN_SLOTS_PER_KEY slots per key, power-of-two number of groups, at least 64 groups
     uint64_t groups = 64;
-    while (groups * 4 < n * 2 + 8) groups <<= 1;
+    while (groups * DCN_GROUP_SLOTS < n * DCN_SLOTS_PER_KEY + 8) groups <<= 1;
     if (groups > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
     idx->n_groups = groups;
-    DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * 4 * sizeof(uint64_t)));
-    DCN_HIP(hipMemset(idx->d_slots, 0, groups * 4 * sizeof(uint64_t)));
+    DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    DCN_HIP(hipMemset(idx->d_slots, 0, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     unsigned long long *d_new = nullptr;
     uint32_t *d_zero = nullptr;
     DCN_HIP(hipMalloc((void **)&d_new, sizeof(unsigned long long)));

@@ -9,7 +9,7 @@ import json,sys
 v=sys.argv[1]
 try:
     d=json.load(open(f"gpurun_out/var_{v}.json"))
-    print(f"{v:18s} value={d['value']:.0f} ms/step={d['ms_per_step']:.3f} scan={d['stage_ms_per_step']['scan']:.3f} kept={d['kept_fraction']:.4f}")
+    print(f"{v:18s} value={d['value']:.0f} ms/step={d['ms_per_step']:.3f} scan={d['stage_ms_per_launch']['scan']:.3f} kept={d['kept_fraction']:.4f}")
 except Exception as e:
     print(v, "no result", e)
 PY

@@ -89,6 +89,80 @@ def make_reads(genome_dev, n_reads, seed, device, host_frac=0.5, sub=0.005, p_n=
     return out.reshape(-1)
 
 
+def _revcomp_ascii(t):
+    """reverse complement of a (n, L) uint8 ACGT/N tensor"""
+    comp = torch.arange(256, dtype=torch.uint8, device=t.device)
+    for a, b in (("A", "T"), ("C", "G"), ("G", "C"), ("T", "A")):
+        comp[ord(a)] = ord(b)
+    return comp[t.long()].flip(1)
+
+
+def make_pairs(genome_dev, n_pairs, seed, device, host_frac=0.5, sub=0.005, p_n=0.001):
+    """2 x READ_LEN pairs (mate 2 reverse-complemented, insert 350 +- 50): rows 2i, 2i+1 are the mates of pair i."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty((n_pairs, 2, READ_LEN), dtype=torch.uint8, device=device)
+    ar = torch.arange(READ_LEN, device=device)
+    chunk = 1 << 18
+    for a in range(0, n_pairs, chunk):
+        m = min(chunk, n_pairs - a)
+        is_host = torch.rand(m, generator=g, device=device) < host_frac
+        ins = (350 + 50 * torch.randn(m, generator=g, device=device)).clamp(READ_LEN, 600).long()
+        starts = torch.randint(0, genome_dev.numel() - 700, (m,), generator=g, device=device)
+        m1 = genome_dev[starts[:, None] + ar[None, :]]
+        m2 = _revcomp_ascii(genome_dev[(starts + ins - READ_LEN)[:, None] + ar[None, :]])
+        both = torch.stack([m1, m2], 1)
+        rnd = alpha[torch.randint(0, 4, (m, 2, READ_LEN), generator=g, device=device)]
+        mut = torch.rand((m, 2, READ_LEN), generator=g, device=device) < sub
+        both = torch.where(mut, rnd, both)
+        nmask = torch.rand((m, 2, READ_LEN), generator=g, device=device) < p_n
+        both = torch.where(nmask, torch.full_like(both, ord("N")), both)
+        out[a:a + m] = torch.where(is_host[:, None, None], both, rnd)
+    return out.reshape(-1)
+
+
+def make_long_reads(genome_dev, total_bases, seed, device, host_frac=0.5, sub=0.05):
+    """ONT-style reads: LogNormal(mu=8.8903, sigma=0.8) lengths (mean 10 kbp) clamped to [200, 500000]; host-derived
+    reads carry 5 % substitutions.  Returns (bases u8[], offsets int64[n+1])."""
+    rng = np.random.default_rng(seed)
+    lens = []
+    tot = 0
+    while tot < total_bases:
+        ln = int(min(500_000, max(200, rng.lognormal(8.8903, 0.8))))
+        ln = min(ln, genome_dev.numel() - 1)
+        lens.append(ln)
+        tot += ln
+    lens = np.array(lens, dtype=np.int64)
+    offsets = np.zeros(len(lens) + 1, np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    alpha = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    out = torch.empty(int(offsets[-1]), dtype=torch.uint8, device=device)
+    is_host = rng.random(len(lens)) < host_frac
+    starts = (rng.random(len(lens)) * (genome_dev.numel() - lens)).astype(np.int64)
+    # chunks of reads holding <= 32 M bases: per-base source index = start[read] + position in read
+    a = 0
+    while a < len(lens):
+        b = a
+        while b < len(lens) and offsets[b + 1] - offsets[a] <= (1 << 25):
+            b += 1
+        b = max(b, a + 1)
+        n = int(offsets[b] - offsets[a])
+        ln_t = torch.from_numpy(lens[a:b]).to(device)
+        rid = torch.repeat_interleave(torch.arange(b - a, device=device), ln_t)
+        pos = torch.arange(n, device=device) - torch.from_numpy(offsets[a:b] - offsets[a]).to(device)[rid]
+        src = genome_dev[torch.from_numpy(starts[a:b]).to(device)[rid] + pos]
+        rnd = alpha[torch.randint(0, 4, (n,), generator=g, device=device)]
+        mut = torch.rand(n, generator=g, device=device) < sub
+        src = torch.where(mut, rnd, src)
+        host = torch.from_numpy(is_host[a:b]).to(device)[rid]
+        out[int(offsets[a]):int(offsets[b])] = torch.where(host, src, rnd)
+        a = b
+    return out, torch.from_numpy(offsets).to(device)
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box gives a
     1-GPU job 16 of its 256 hardware threads)."""
@@ -146,6 +220,9 @@ def main():
     ap.add_argument("--contexts", type=int, default=1,
                     help="pipeline contexts per GPU: the step's batch is split into this many sub-batches, each on its "
                          "own context/stream, so pack+plan of one overlap the scan of another")
+    ap.add_argument("--workload", choices=["short", "paired", "long"], default="short",
+                    help="short: configs[1] 150 bp single reads (the headline); paired: configs[3] 2x150 bp --deplete; "
+                         "long: configs[2] ONT-style lognormal reads, mean 10 kbp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -178,24 +255,50 @@ def main():
     log(f"device table: {index.n_keys:,} distinct keys in {index_build_s:.1f} s")
 
     # ---- reads: resident in HBM before the timed region -------------------------------------------------------
-    n_reads = args.reads
-    n_bases = n_reads * READ_LEN
-    d_bases = make_reads(genome_dev, n_reads, 5 + rank, device)
-    d_offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * READ_LEN
-    d_keep = torch.zeros(n_reads, dtype=torch.uint8, device=device)
-    d_hits = torch.zeros(n_reads, dtype=torch.int32, device=device)
-    d_total = torch.zeros(n_reads, dtype=torch.int32, device=device)
     params = {"abs": 2, "rel": 0.01, "deplete": False}
-    C = max(1, args.contexts)
+    d_unit_id = None
+    if args.workload == "short":
+        n_reads = args.reads
+        d_bases = make_reads(genome_dev, n_reads, 5 + rank, device)
+        d_offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * READ_LEN
+        n_units = n_reads
+    elif args.workload == "paired":
+        n_reads = args.reads // 2 * 2
+        d_bases = make_pairs(genome_dev, n_reads // 2, 7 + rank, device)
+        d_offsets = torch.arange(n_reads + 1, dtype=torch.int64, device=device) * READ_LEN
+        d_unit_id = (torch.arange(n_reads, dtype=torch.int32, device=device) // 2).contiguous()
+        n_units = n_reads // 2
+        params["deplete"] = True
+    else:
+        d_bases, d_offsets = make_long_reads(genome_dev, args.reads * READ_LEN, 6 + rank, device)
+        n_reads = d_offsets.numel() - 1
+        n_units = n_reads
+    n_bases = int(d_bases.numel())
+    d_keep = torch.zeros(n_units, dtype=torch.uint8, device=device)
+    d_hits = torch.zeros(n_units, dtype=torch.int32, device=device)
+    d_total = torch.zeros(n_units, dtype=torch.int32, device=device)
+    C = max(1, args.contexts) if args.workload == "short" else 1
     bounds = [(n_reads * c // C) // 8 * 8 for c in range(C)] + [n_reads]  # sub-batch starts stay 16-byte aligned
-    procs = [dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"],
-                                 deplete=params["deplete"], max_batch_bases=(bounds[c + 1] - bounds[c]) * READ_LEN,
-                                 max_batch_reads=bounds[c + 1] - bounds[c]) for c in range(C)]
+    if C == 1:
+        procs = [dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"],
+                                     deplete=params["deplete"], max_batch_bases=n_bases, max_batch_reads=n_reads)]
+        if args.workload == "long":
+            procs[0].reserve_records(n_bases // 6)  # ~1 hit record per 16 bp when half the reads are host-derived
+    else:
+        procs = [dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"],
+                                     deplete=params["deplete"], max_batch_bases=(bounds[c + 1] - bounds[c]) * READ_LEN,
+                                     max_batch_reads=bounds[c + 1] - bounds[c]) for c in range(C)]
     d_sub_offsets = [torch.arange(bounds[c + 1] - bounds[c] + 1, dtype=torch.int64, device=device) * READ_LEN
-                     for c in range(C)]
+                     for c in range(C)] if C > 1 else None
     torch.cuda.synchronize()
 
     def step():
+        if C == 1:
+            procs[0].filter_batch_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, d_keep.data_ptr(),
+                                         d_hits.data_ptr(), d_total.data_ptr(),
+                                         d_unit_id=d_unit_id.data_ptr() if d_unit_id is not None else None,
+                                         n_units=n_units)
+            return
         for c, proc in enumerate(procs):
             a, b = bounds[c], bounds[c + 1]
             proc.filter_batch_device(d_bases.data_ptr() + a * READ_LEN, d_sub_offsets[c].data_ptr(), b - a,
@@ -246,7 +349,8 @@ def main():
 
     if rank == 0:
         total_bp = counters[2]
-        assert total_bp == n_bases * args.steps * world, (total_bp, n_bases, args.steps, world)
+        if args.workload != "long" or world == 1:  # long reads: every rank draws its own lengths
+            assert total_bp == n_bases * args.steps * world, (total_bp, n_bases, args.steps, world)
         scan_ms = stage_ms["scan"] / max(n_prof, 1)
         # per scan launch (= per sub-batch): SURVEY.md 8d: 2-bit base + mask bit, 8 B per probed minimizer
         algo_bytes = (0.375 * n_bases + 8.0 * n_minimizers) / C
@@ -265,8 +369,10 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
-                "index_keys": int(index.n_keys), "reads_per_batch_per_gpu": n_reads, "read_len": READ_LEN,
+                "workload": {"short": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
+                             "paired": "configs[3]: paired 2x150 bp --deplete vs panhuman-1-sized index, inputs resident in HBM as ASCII",
+                             "long": "configs[2]: ONT-style lognormal reads (mean 10 kbp) vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII"}[args.workload],
+                "index_keys": int(index.n_keys), "reads_per_batch_per_gpu": n_reads, "bases_per_batch_per_gpu": n_bases,
                 "k": K, "w": W, "host_fraction": 0.5, "parallelism": f"reads sharded x{world}, index replicated",
                 "contexts_per_gpu": C,
             },
@@ -278,10 +384,10 @@ def main():
                 "minimizers_per_launch": n_minimizers // C,
             },
             "stage_ms_per_launch": {k_: v / max(n_prof, 1) for k_, v in stage_ms.items()},
-            "kept_fraction": kept / n_reads,
+            "kept_fraction": kept / n_units,
             "index_build_s": index_build_s,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "short":
             bases_np = d_bases[:min(n_reads, 2_000_000) * READ_LEN].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(keys, bases_np, min(n_reads, 2_000_000), params, d_keep)
         else:

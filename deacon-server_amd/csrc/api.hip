@@ -197,6 +197,7 @@ uint64_t packed_words(uint64_t max_bases) { return DCN_FRONT_PAD + 2 * ((max_bas
 uint64_t mask_words(uint64_t max_bases) { return DCN_FRONT_PAD + (max_bases + 31) / 32 + DCN_TAIL_PAD; }
 
 int alloc_records(dcn_ctx *c, uint64_t n_records) {
+    n_records = (n_records + DCN_REC_SHARDS - 1) / DCN_REC_SHARDS * DCN_REC_SHARDS;
     if (n_records > (1ull << 29)) return dcn_fail(DCN_ERR_CAPACITY, "more than 2^29 hit records per batch: use smaller batches");
     if (c->d_rec_unit) hipFree(c->d_rec_unit);
     if (c->d_rec_hash) hipFree(c->d_rec_hash);
@@ -395,7 +396,11 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     c->batch_pending = false;
     DCN_HIP(hipMemcpy(c->h_status, c->d_status, sizeof(dcn_status), hipMemcpyDeviceToHost));
     if (c->h_status->rec_overflow) {
-        uint64_t need = c->h_status->rec_count;
+        // size the retry for the fullest shard (shards fill unevenly)
+        uint64_t need = 0;
+        for (uint32_t sidx = 0; sidx < DCN_REC_SHARDS; ++sidx)
+            need = std::max<uint64_t>(need, c->h_status->rec_count[sidx]);
+        need *= DCN_REC_SHARDS;
         if (needed_records) *needed_records = need;
         return dcn_fail(DCN_ERR_CAPACITY, "hit-record scratch overflow: need " + std::to_string(need) +
                                               " records, have " + std::to_string(c->rec_capacity) +

@@ -86,11 +86,14 @@ struct dcn_tile {
     uint32_t flags;      // bit0: has carry window (first scanned window only seeds the dedup state)
 };
 
+// The (unit, hash) hit-record buffer is split into DCN_REC_SHARDS equal segments, each with its own append
+// counter (workgroup b appends to shard b % DCN_REC_SHARDS): one global word takes only ~88 atomics/us.
+constexpr uint32_t DCN_REC_SHARDS = 64;
+
 // status words written by the device pipeline (one per ctx, zeroed per batch)
 struct dcn_status {
-    unsigned long long rec_count; // hit records appended
-    unsigned long long set_slots; // slots needed by the distinct pass
-    uint32_t rec_overflow;        // records dropped: rec_capacity too small
+    unsigned long long rec_count[DCN_REC_SHARDS]; // hit records appended per shard (may exceed the segment size)
+    uint32_t rec_overflow;                        // records dropped: a segment of the record buffer was too small
     uint32_t n_tiles;
     unsigned long long stats[DCN_N_STATS];
 };
@@ -116,7 +119,7 @@ struct dcn_scan_args {
     uint32_t *g_hitcnt; // per unit, number of hit records
     uint32_t *rec_unit;
     uint64_t *rec_hash;
-    uint64_t rec_capacity;
+    uint64_t rec_capacity; // total; each shard owns rec_capacity / DCN_REC_SHARDS consecutive entries
     dcn_status *status;
     // dump mode (dcn_minimizer_hashes_batch): per emitted minimizer
     uint64_t *dump_hash;

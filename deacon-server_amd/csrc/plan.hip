@@ -78,33 +78,61 @@ __global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots
 }
 
 __global__ __launch_bounds__(256) void distinct_insert_kernel(dcn_distinct_args a) {
-    unsigned long long n = a.status->rec_count;
-    if (n > a.rec_capacity) n = a.rec_capacity;
     uint64_t total_slots = a.set_off[a.n_units];
     if (total_slots > a.set_capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.status->rec_overflow = 1;
         return;
     }
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t u = a.rec_unit[i];
-        uint64_t h = a.rec_hash[i];
-        if (h == 0) { // 0 marks an empty slot: a zero hash is tracked by a per-unit flag
-            if (atomicExch(&a.g_zero[u], 1u) == 0u) atomicAdd(&a.g_distinct[u], 1u);
-            continue;
-        }
-        uint32_t cap = a.set_off[u + 1] - a.set_off[u];
-        unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
-        uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
-        uint32_t slot = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x85EBCA6Bu) & (cap - 1);
-        for (;;) {
-            unsigned long long old = atomicCAS(&region[slot], 0ull, (unsigned long long)h);
-            if (old == 0) {
-                atomicAdd(&a.g_distinct[u], 1u);
-                break;
+    const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1;
+    // blocks are dealt round-robin over the shards; within a shard a grid-stride loop in whole waves
+    for (uint32_t shard = blockIdx.x % DCN_REC_SHARDS; shard < DCN_REC_SHARDS; shard += DCN_REC_SHARDS) {
+        unsigned long long n = a.status->rec_count[shard];
+        if (n > seg) n = seg;
+        const uint32_t blocks_per_shard = gridDim.x / DCN_REC_SHARDS;
+        const uint64_t stride = (uint64_t)blocks_per_shard * blockDim.x;
+        const uint64_t first = (uint64_t)(blockIdx.x / DCN_REC_SHARDS) * blockDim.x + threadIdx.x;
+        for (uint64_t i0 = first - lane; i0 < n; i0 += stride) { // i0: wave-uniform base
+            const uint64_t i = i0 + lane;
+            bool fresh = false;
+            uint32_t u = 0xFFFFFFFFu;
+            if (i < n) {
+                u = a.rec_unit[shard * seg + i];
+                uint64_t h = a.rec_hash[shard * seg + i];
+                if (h == 0) { // 0 marks an empty slot: a zero hash is tracked by a per-unit flag
+                    fresh = atomicExch(&a.g_zero[u], 1u) == 0u;
+                } else {
+                    uint32_t cap = a.set_off[u + 1] - a.set_off[u];
+                    unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
+                    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+                    uint32_t slot = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x85EBCA6Bu) & (cap - 1);
+                    for (;;) {
+                        unsigned long long old = atomicCAS(&region[slot], 0ull, (unsigned long long)h);
+                        if (old == 0) {
+                            fresh = true;
+                            break;
+                        }
+                        if (old == h) break;
+                        slot = (slot + 1) & (cap - 1);
+                    }
+                }
             }
-            if (old == h) break;
-            slot = (slot + 1) & (cap - 1);
+            // one atomicAdd per run of equal unit among the lanes with a new key (records of a wave round are
+            // adjacent and mostly of one unit)
+            const unsigned long long fb = __ballot(fresh);
+            if (fb) {
+                const unsigned long long below = fb & lt;
+                const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
+                const uint32_t prev_u = __shfl(u, prev_lane, 64);
+                const bool run_head = fresh && (below == 0 || prev_u != u);
+                const unsigned long long hm = __ballot(run_head);
+                if (run_head) {
+                    const unsigned long long later = hm & ~((2ull << lane) - 1);
+                    const unsigned long long upto = later ? ((1ull << (__ffsll((long long)later) - 1)) - 1) : ~0ull;
+                    atomicAdd(&a.g_distinct[u], (uint32_t)__popcll(fb & upto & ~lt));
+                }
+            }
         }
     }
 }
@@ -161,6 +189,8 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
 __global__ __launch_bounds__(256) void probe_hashes_kernel(dcn_probe_hashes_args a) {
     uint64_t n = a.n_hashes;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t shard = blockIdx.x % DCN_REC_SHARDS;
+    const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t h = a.hashes[i];
         if (!dcn_table_contains_dev(a.table, h)) continue;
@@ -171,14 +201,14 @@ __global__ __launch_bounds__(256) void probe_hashes_kernel(dcn_probe_hashes_args
             if (a.hash_offsets[mid] <= i) lo = mid;
             else hi = mid - 1;
         }
-        unsigned long long r = atomicAdd(&a.status->rec_count, 1ull);
-        if (r < a.rec_capacity) {
-            a.rec_unit[r] = lo;
-            a.rec_hash[r] = h;
-            atomicAdd(&a.g_hitcnt[lo], 1u);
+        unsigned long long r = atomicAdd(&a.status->rec_count[shard], 1ull);
+        if (r < seg) {
+            a.rec_unit[shard * seg + r] = lo;
+            a.rec_hash[shard * seg + r] = h;
         } else {
             a.status->rec_overflow = 1;
         }
+        atomicAdd(&a.g_hitcnt[lo], 1u);
     }
 }
 
@@ -215,7 +245,7 @@ int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *
     if (rc != DCN_OK) return rc;
     hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_off, a.n_units,
                        a.set_capacity);
-    hipLaunchKernelGGL(distinct_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(distinct_insert_kernel, dim3(DCN_REC_SHARDS * 32), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }

@@ -344,24 +344,40 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                     n_ring += nh;
                     __syncthreads();
                 }
-                // hits of every other unit: exported as (unit, hash) records
+                // hits of every other unit: exported as (unit, hash) records into this workgroup's shard of the
+                // record buffer; the per-unit record count is added once per run of equal unit, not per record
                 {
                     const bool rec = hit[u] && !lok;
-                    unsigned long long rb = __ballot(rec);
+                    const unsigned long long rb = __ballot(rec);
                     if (rb) { // wave-uniform
-                        uint32_t nrec = (uint32_t)__popcll(rb);
+                        const unsigned long long lt = (1ull << lane) - 1;
+                        const uint32_t nrec = (uint32_t)__popcll(rb);
+                        const uint32_t shard = blockIdx.x % DCN_REC_SHARDS;
+                        const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
                         unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(&a.status->rec_count, (unsigned long long)nrec);
+                        if (lane == 0) base = atomicAdd(&a.status->rec_count[shard], (unsigned long long)nrec);
                         base = __shfl(base, 0, 64);
+                        const uint32_t rank = (uint32_t)__popcll(rb & lt);
+                        const unsigned long long below = rb & lt;
+                        const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
+                        const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
+                        const bool run_head = rec && (below == 0 || prev_us != o_uslot[u]);
+                        const unsigned long long hm = __ballot(run_head);
                         if (rec) {
-                            unsigned long long ridx = base + (uint32_t)__popcll(rb & ((1ull << lane) - 1));
-                            if (ridx < a.rec_capacity) {
-                                uint32_t gu = sh.unit_of[o_uslot[u]];
-                                a.rec_unit[ridx] = gu;
-                                a.rec_hash[ridx] = hash[u];
-                                atomicAdd(&a.g_hitcnt[gu], 1u);
+                            const unsigned long long ridx = base + rank;
+                            const uint32_t gu = sh.unit_of[o_uslot[u]];
+                            if (ridx < seg) {
+                                a.rec_unit[shard * seg + ridx] = gu;
+                                a.rec_hash[shard * seg + ridx] = hash[u];
                             } else {
                                 a.status->rec_overflow = 1;
+                            }
+                            if (run_head) {
+                                // run = rec lanes from this head up to the next head
+                                const unsigned long long later_heads = hm & ~((2ull << lane) - 1);
+                                const uint32_t end_rank = later_heads ? (uint32_t)__popcll(rb & ((1ull << (__ffsll((long long)later_heads) - 1)) - 1))
+                                                                      : nrec;
+                                atomicAdd(&a.g_hitcnt[gu], end_rank - rank);
                             }
                         }
                     }

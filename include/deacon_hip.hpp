@@ -1,0 +1,261 @@
+// deacon_hip.hpp -- header-only C++ host layer over the C ABI of deacon_hip.h.
+//
+// Mirrors the reference's filter interface (crate deacon 0.10.0) so that host code reads like the Rust it
+// replaces; names, argument meaning and error behaviour follow the cited items (paths under the reference's src/):
+//
+//   deacon::Index                       index::load_minimizer_hashes + IndexHeader      index.rs:17-54, 80-107
+//   deacon::FilterConfig                FilterConfig defaults                            lib.rs:90-109
+//   deacon::FilterProcessor             local_filter::FilterProcessor                    local_filter.rs:153-285
+//     .should_keep_sequence(seq)        -> (keep, hit_count, num_minimizers)             local_filter.rs:221-252
+//     .should_keep_pair(seq1, seq2)                                                      local_filter.rs:254-285
+//     .filter_batch(reads[, paired])    the paraseq per-record loop over one batch       local_filter.rs:346-528
+//     .stats()                          ProcessingStats                                  local_filter.rs:179-187
+//   deacon::get_minimizer_hashes_and_positions                                           filter_common.rs:211-310
+//   deacon::unpaired_should_keep / paired_should_keep                                    remote_filter.rs:230-301
+//
+// Errors: the reference returns anyhow::Result up to main; here every failing C call throws deacon::Error carrying
+// the code and dcn_last_error().  Nothing in this header computes: all arithmetic happens in libdeacon_hip.so.
+#ifndef DEACON_HIP_HPP
+#define DEACON_HIP_HPP
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "deacon_hip.h"
+
+namespace deacon {
+
+constexpr uint8_t DEFAULT_KMER_LENGTH = 31;  // minimizers.rs:4
+constexpr uint8_t DEFAULT_WINDOW_SIZE = 15;  // minimizers.rs:5
+
+class Error : public std::runtime_error {
+  public:
+    Error(int code, const std::string &what) : std::runtime_error(what), code_(code) {}
+    int code() const { return code_; }
+
+  private:
+    int code_;
+};
+
+inline void check(int rc) {
+    if (rc != DCN_OK) throw Error(rc, std::string("deacon_hip error ") + std::to_string(rc) + ": " + dcn_last_error());
+}
+
+// (keep, hit_count, num_minimizers): the tuple should_keep_* returns, minus the debug k-mer strings
+using Decision = std::tuple<bool, std::size_t, std::size_t>;
+
+struct IndexHeader {  // index.rs:17-22
+    uint8_t format_version = 2;
+    uint8_t kmer_length = DEFAULT_KMER_LENGTH;
+    uint8_t window_size = DEFAULT_WINDOW_SIZE;
+};
+
+class Index {
+  public:
+    // index.rs:80-107: load a deacon index file into the device-resident set
+    static Index load(const std::string &path, int device = 0) {
+        dcn_index *h = nullptr;
+        check(dcn_index_from_file(path.c_str(), device, &h));
+        return Index(h);
+    }
+    // the same from minimizer hashes already in memory (what index::build holds before write_minimizers)
+    static Index from_hashes(const std::vector<uint64_t> &hashes, uint8_t kmer_length = DEFAULT_KMER_LENGTH,
+                             uint8_t window_size = DEFAULT_WINDOW_SIZE, int device = 0) {
+        dcn_index *h = nullptr;
+        check(dcn_index_from_keys(hashes.data(), hashes.size(), kmer_length, window_size, device, &h));
+        return Index(h);
+    }
+    Index(Index &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+    Index &operator=(Index &&o) noexcept {
+        if (this != &o) {
+            reset();
+            h_ = std::exchange(o.h_, nullptr);
+        }
+        return *this;
+    }
+    Index(const Index &) = delete;
+    Index &operator=(const Index &) = delete;
+    ~Index() { reset(); }
+
+    IndexHeader header() const {
+        IndexHeader hd;
+        check(dcn_index_header(h_, &hd.kmer_length, &hd.window_size, nullptr));
+        return hd;
+    }
+    uint64_t len() const {  // number of distinct minimizers (`deacon index info`, index.rs:539-560)
+        uint64_t n = 0;
+        check(dcn_index_header(h_, nullptr, nullptr, &n));
+        return n;
+    }
+    std::vector<bool> contains(const std::vector<uint64_t> &hashes) const {  // FxHashSet::contains
+        std::vector<uint8_t> out(hashes.size());
+        check(dcn_index_contains(h_, hashes.data(), hashes.size(), out.data()));
+        return std::vector<bool>(out.begin(), out.end());
+    }
+    const dcn_index *raw() const { return h_; }
+
+  private:
+    explicit Index(dcn_index *h) : h_(h) {}
+    void reset() {
+        if (h_) dcn_index_destroy(h_);
+        h_ = nullptr;
+    }
+    dcn_index *h_ = nullptr;
+};
+
+struct FilterConfig {  // the decision-relevant fields of lib.rs:39-87 with their defaults (lib.rs:90-109)
+    std::size_t abs_threshold = 2;
+    double rel_threshold = 0.01;
+    std::size_t prefix_length = 0;
+    bool deplete = false;
+    // sizing of the device pipeline (no counterpart in the reference)
+    uint64_t max_batch_bases = 1ull << 26;
+    uint32_t max_batch_reads = 1u << 20;
+};
+
+struct ProcessingStats {  // local_filter.rs:179-187
+    uint64_t total_seqs = 0, filtered_seqs = 0, total_bp = 0, output_bp = 0, filtered_bp = 0, output_seq_counter = 0;
+};
+
+class FilterProcessor {
+  public:
+    FilterProcessor(const Index &index, const FilterConfig &config) : config_(config) {
+        check(dcn_ctx_create(index.raw(), config.max_batch_bases, config.max_batch_reads, &ctx_));
+    }
+    FilterProcessor(const FilterProcessor &) = delete;
+    FilterProcessor &operator=(const FilterProcessor &) = delete;
+    ~FilterProcessor() {
+        if (ctx_) dcn_ctx_destroy(ctx_);
+    }
+
+    // local_filter.rs:221-252
+    Decision should_keep_sequence(std::string_view seq) {
+        auto r = filter_batch({seq}, false);
+        return r.at(0);
+    }
+    // local_filter.rs:254-285: mate 1 then mate 2, hits distinct across both mates, one decision
+    Decision should_keep_pair(std::string_view seq1, std::string_view seq2) {
+        auto r = filter_batch({seq1, seq2}, true);
+        return r.at(0);
+    }
+    // One batch of records; paired: reads 2i and 2i+1 are the mates of pair i (a trailing single read is its own
+    // unit).  Returns one Decision per unit, in input order.
+    std::vector<Decision> filter_batch(const std::vector<std::string_view> &reads, bool paired) {
+        bases_.clear();
+        offsets_.assign(1, 0);
+        unit_id_.clear();
+        for (std::size_t i = 0; i < reads.size(); ++i) {
+            bases_.insert(bases_.end(), reads[i].begin(), reads[i].end());
+            offsets_.push_back(bases_.size());
+            if (paired) unit_id_.push_back(static_cast<uint32_t>(i / 2));
+        }
+        std::size_t n_units = paired ? (reads.size() + 1) / 2 : reads.size();
+        keep_.assign(n_units, 0);
+        hits_.assign(n_units, 0);
+        total_.assign(n_units, 0);
+        dcn_params p = params();
+        check(dcn_filter_batch(ctx_, bases_.data(), offsets_.data(), paired ? unit_id_.data() : nullptr,
+                               static_cast<uint32_t>(reads.size()), &p, keep_.data(), hits_.data(), total_.data()));
+        std::vector<Decision> out(n_units);
+        for (std::size_t u = 0; u < n_units; ++u) out[u] = Decision(keep_[u] != 0, hits_[u], total_[u]);
+        return out;
+    }
+    // Zero-copy form of the batch seam: concatenated bases + offsets (+ optional unit ids), outputs per unit.
+    void filter_batch(const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id, uint32_t n_reads,
+                      uint8_t *keep, uint32_t *hits, uint32_t *total) {
+        dcn_params p = params();
+        check(dcn_filter_batch(ctx_, bases, offsets, unit_id, n_reads, &p, keep, hits, total));
+    }
+
+    ProcessingStats stats() {
+        std::array<uint64_t, DCN_N_STATS> c{};
+        check(dcn_ctx_stats(ctx_, c.data()));
+        ProcessingStats s;
+        s.total_seqs = c[DCN_STAT_TOTAL_SEQS];
+        s.filtered_seqs = c[DCN_STAT_FILTERED_SEQS];
+        s.total_bp = c[DCN_STAT_TOTAL_BP];
+        s.output_bp = c[DCN_STAT_OUTPUT_BP];
+        s.filtered_bp = c[DCN_STAT_FILTERED_BP];
+        s.output_seq_counter = c[DCN_STAT_OUTPUT_SEQ_COUNTER];
+        return s;
+    }
+
+    FilterConfig &config() { return config_; }
+    dcn_ctx *raw() { return ctx_; }
+
+    dcn_params params() const {
+        dcn_params p;
+        p.abs_threshold = config_.abs_threshold;
+        p.rel_threshold = config_.rel_threshold;
+        p.prefix_length = config_.prefix_length;
+        p.deplete = config_.deplete ? 1u : 0u;
+        p.reserved = 0;
+        return p;
+    }
+
+  private:
+    FilterConfig config_;
+    dcn_ctx *ctx_ = nullptr;
+    std::vector<uint8_t> bases_, keep_;
+    std::vector<uint64_t> offsets_;
+    std::vector<uint32_t> unit_id_, hits_, total_;
+};
+
+// filter_common.rs:211-310 for one read: (minimizer hashes, positions) after the ACGT filter
+inline std::pair<std::vector<uint64_t>, std::vector<uint32_t>> get_minimizer_hashes_and_positions(
+    FilterProcessor &proc, std::string_view seq, std::size_t prefix_length = 0) {
+    uint64_t offsets[2] = {0, seq.size()};
+    uint64_t out_off[2] = {0, 0};
+    std::vector<uint64_t> h(seq.size() + 1);
+    std::vector<uint32_t> p(seq.size() + 1);
+    check(dcn_minimizer_hashes_batch(proc.raw(), reinterpret_cast<const uint8_t *>(seq.data()), offsets, 1,
+                                     prefix_length, out_off, h.data(), p.data(), h.size()));
+    h.resize(out_off[1]);
+    p.resize(out_off[1]);
+    return {std::move(h), std::move(p)};
+}
+
+namespace detail {
+inline std::vector<Decision> should_keep(FilterProcessor &proc, const std::vector<std::vector<uint64_t>> &input,
+                                         std::size_t abs_threshold, double rel_threshold, bool deplete) {
+    std::vector<uint64_t> flat, off(1, 0);
+    for (const auto &v : input) {
+        flat.insert(flat.end(), v.begin(), v.end());
+        off.push_back(flat.size());
+    }
+    std::vector<uint8_t> keep(input.size());
+    std::vector<uint32_t> hits(input.size()), total(input.size());
+    dcn_params p = proc.params();
+    p.abs_threshold = abs_threshold;
+    p.rel_threshold = rel_threshold;
+    p.deplete = deplete ? 1u : 0u;
+    check(dcn_should_keep_hashes(proc.raw(), flat.data(), off.data(), static_cast<uint32_t>(input.size()), &p,
+                                 keep.data(), hits.data(), total.data()));
+    std::vector<Decision> out(input.size());
+    for (std::size_t u = 0; u < input.size(); ++u) out[u] = Decision(keep[u] != 0, hits[u], total[u]);
+    return out;
+}
+}  // namespace detail
+
+// remote_filter.rs:230-264: one Vec<u64> of minimizer hashes per read
+inline std::vector<Decision> unpaired_should_keep(FilterProcessor &proc,
+                                                  const std::vector<std::vector<uint64_t>> &input_minimizers,
+                                                  std::size_t abs_threshold, double rel_threshold, bool deplete) {
+    return detail::should_keep(proc, input_minimizers, abs_threshold, rel_threshold, deplete);
+}
+
+// remote_filter.rs:266-301: one Vec<u64> per pair (both mates' hashes concatenated)
+inline std::vector<Decision> paired_should_keep(FilterProcessor &proc,
+                                                const std::vector<std::vector<uint64_t>> &input_minimizers,
+                                                std::size_t abs_threshold, double rel_threshold, bool deplete) {
+    return detail::should_keep(proc, input_minimizers, abs_threshold, rel_threshold, deplete);
+}
+
+}  // namespace deacon
+#endif  // DEACON_HIP_HPP

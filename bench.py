@@ -355,6 +355,15 @@ def main():
         # per scan launch (= per sub-batch): SURVEY.md 8d: 2-bit base + mask bit, 8 B per probed minimizer
         algo_bytes = (0.375 * n_bases + 8.0 * n_minimizers) / C
         achieved = algo_bytes / (scan_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per scan launch from the committed PMC passes (same workload only)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            wlk = tr["workload"]
+            if (args.workload == wlk["workload"] and n_reads == wlk["reads_per_batch"] and C == 1
+                    and int(index.n_keys) == wlk["index_keys"]):
+                traffic = tr["scan_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "Mbp/s filtered (k=31,w=15 vs panhuman-1-sized index), decisions bit-exact vs CPU",
             "value": total_bp / elapsed / 1e6,
@@ -379,7 +388,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "scan_kernel<15> (scan+hash+probe+distinct)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_ms,
                 "minimizers_per_launch": n_minimizers // C,
             },

@@ -93,6 +93,59 @@ extern "C" int dcn_index_from_file(const char *path, int device, dcn_index **out
     return dcn_index_from_keys(keys.data(), keys.size(), k, w, device, out);
 }
 
+int dcn_write_index_file(const char *path, uint8_t k, uint8_t w, const uint64_t *keys, uint64_t n); // index_file.cpp
+int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seqs, float entropy_threshold,
+                         uint64_t capacity_keys, dcn_index *idx); // below, needs dcn_ctx
+
+extern "C" int dcn_index_build(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seqs, uint8_t k, uint8_t w,
+                               float entropy_threshold, uint64_t capacity_keys, int device, dcn_index **out) {
+    if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    int rc = check_kw(k, w);
+    if (rc != DCN_OK) return rc;
+    if (n_seqs > 0 && !offsets) return dcn_fail(DCN_ERR_ARG, "offsets is NULL");
+    if (n_seqs > 0 && offsets[n_seqs] > 0 && !bases) return dcn_fail(DCN_ERR_ARG, "bases is NULL");
+    if (!(entropy_threshold >= 0.0f && entropy_threshold <= 1.0f)) return dcn_fail(DCN_ERR_ARG, "entropy_threshold must be in [0, 1]");
+    int ndev = 0;
+    rc = dcn_device_count(&ndev);
+    if (rc != DCN_OK) return rc;
+    if (device < 0 || device >= ndev) return dcn_fail(DCN_ERR_ARG, "no such HIP device");
+    dcn_index *idx = new (std::nothrow) dcn_index();
+    if (!idx) return dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
+    idx->device = device;
+    idx->k = k;
+    idx->w = w;
+    rc = dcn_table_alloc(idx, std::max<uint64_t>(capacity_keys, 1024));
+    if (rc == DCN_OK) rc = dcn_build_index_impl(bases, offsets, n_seqs, entropy_threshold, capacity_keys, idx);
+    if (rc != DCN_OK) {
+        if (idx->d_slots) hipFree(idx->d_slots);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return DCN_OK;
+}
+
+extern "C" int dcn_index_keys(const dcn_index *index, uint64_t *out, uint64_t capacity, uint64_t *n) {
+    if (!index || !n) return dcn_fail(DCN_ERR_ARG, "index/n is NULL");
+    if (capacity > 0 && !out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
+    return dcn_table_export(index, out, capacity, n);
+}
+
+extern "C" int dcn_index_write_file(const dcn_index *index, const char *path) {
+    if (!index || !path) return dcn_fail(DCN_ERR_ARG, "index/path is NULL");
+    std::vector<uint64_t> keys;
+    try {
+        keys.resize(index->n_keys);
+    } catch (...) {
+        return dcn_fail(DCN_ERR_NOMEM, "index too large for host memory");
+    }
+    uint64_t n = 0;
+    int rc = dcn_table_export(index, keys.data(), keys.size(), &n);
+    if (rc != DCN_OK) return rc;
+    return dcn_write_index_file(path, index->k, index->w, keys.data(), n);
+}
+
 extern "C" int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n_keys) {
     if (!index) return dcn_fail(DCN_ERR_ARG, "index is NULL");
     if (k) *k = index->k;
@@ -824,5 +877,125 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
     hipStreamSynchronize(c->stream);
     hipFree(d_hashes);
     hipFree(d_hoff);
+    return rc;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// index build (f1): chunks of sequence pieces -> pack (index-side codes) -> plan -> scan in dump mode -> insert
+// ----------------------------------------------------------------------------------------------------
+int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seqs, float entropy_threshold,
+                         uint64_t capacity_keys, dcn_index *idx) {
+    (void)capacity_keys;
+    if (n_seqs == 0) return DCN_OK;
+    if (offsets[0] != 0) return dcn_fail(DCN_ERR_ARG, "offsets[0] must be 0");
+    const uint32_t k = idx->k, l = (uint32_t)idx->k + idx->w - 1;
+    // a piece is a range of one sequence; a sequence longer than the chunk is cut into pieces overlapping by
+    // l-1 bases, which yields every window exactly once (an extra duplicate at a seam merges in the set)
+    uint64_t chunk_bases = 1ull << 27;
+    if (const char *cb = getenv("DCN_BUILD_CHUNK_BASES")) {
+        long long v = atoll(cb);
+        if (v >= 4096) chunk_bases = (uint64_t)v;
+    }
+    const uint32_t max_pieces = 1u << 16;
+    dcn_ctx *c = nullptr;
+    DCN_TRY(dcn_ctx_create(idx, chunk_bases, max_pieces, &c));
+    int rc = DCN_OK;
+    auto body = [&]() -> int {
+        DCN_TRY(dev_alloc(&c->d_dump_hash, c->max_bases + 2, "dump_hash"));
+        DCN_TRY(dev_alloc(&c->d_dump_pos, c->max_bases + 2, "dump_pos"));
+        DCN_TRY(dev_alloc(&c->d_dump_valid, c->max_bases + 2, "dump_valid"));
+        DCN_TRY(dev_alloc(&c->d_dump_count, c->max_tiles, "dump_count"));
+        std::vector<uint64_t> p_off;   // offsets of the pieces inside the chunk buffer
+        std::vector<const uint8_t *> p_src;
+        std::vector<uint64_t> p_len;
+        auto run_chunk = [&]() -> int {
+            if (p_len.empty()) return DCN_OK;
+            uint32_t np = (uint32_t)p_len.size();
+            p_off.assign(np + 1, 0);
+            for (uint32_t i = 0; i < np; ++i) p_off[i + 1] = p_off[i] + p_len[i];
+            uint64_t nb = p_off[np];
+            for (uint32_t i = 0; i < np; ++i)
+                DCN_TRY(staged_h2d(c, c->d_ascii + p_off[i], p_src[i], p_len[i]));
+            DCN_TRY(staged_h2d(c, c->d_offsets, p_off.data(), (uint64_t)(np + 1) * sizeof(uint64_t)));
+            DCN_HIP(hipEventRecord(c->copy_done, c->copy_stream));
+            DCN_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0));
+            hipStream_t st = c->stream;
+            DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
+            DCN_HIP(hipMemsetAsync(c->d_dump_valid, 0, nb + 2, st));
+            uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
+            DCN_TRY(dcn_launch_pack(c->d_ascii, nb, packed, invmask, st, /*index_side=*/true));
+            dcn_plan_args pa;
+            pa.ascii = c->d_ascii;
+            pa.offsets = c->d_offsets;
+            pa.unit_id = nullptr;
+            pa.n_reads = np;
+            pa.n_units = np;
+            pa.k = idx->k;
+            pa.w = idx->w;
+            pa.prefix_length = 0;
+            pa.tile_windows = c->tile_windows;
+            pa.read_windows = c->d_read_windows;
+            pa.read_tiles = c->d_read_tiles;
+            pa.read_tile_first = c->d_read_tile_first;
+            pa.unit_first_read = c->d_unit_first_read;
+            pa.unit_tile_first = c->d_unit_tile_first;
+            pa.tiles = c->d_tiles;
+            pa.status = c->d_status;
+            DCN_TRY(dcn_launch_plan_reads(pa, st));
+            DCN_TRY(dcn_launch_exclusive_scan(c->d_read_tiles, c->d_read_tile_first, np, c->d_scan_tmp, st));
+            DCN_TRY(dcn_launch_plan_tiles(pa, st));
+            dcn_scan_args sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.packed = packed;
+            sa.invmask = invmask;
+            sa.tiles = c->d_tiles;
+            sa.n_tiles = &c->d_status->n_tiles;
+            sa.table = idx->view();
+            sa.k = idx->k;
+            sa.w = idx->w;
+            sa.status = c->d_status;
+            sa.dump_hash = c->d_dump_hash;
+            sa.dump_pos = c->d_dump_pos;
+            sa.dump_valid = c->d_dump_valid;
+            sa.dump_count = c->d_dump_count;
+            sa.dump_abs = 1;
+            uint64_t tile_bound = std::min<uint64_t>((uint64_t)np + nb / c->tile_windows + 1, c->max_tiles);
+            DCN_TRY(dcn_launch_scan(sa, (uint32_t)tile_bound, true, st));
+            uint64_t n_valid = 0;
+            DCN_TRY(dcn_table_count_valid(c->d_dump_valid, nb, &n_valid, st));
+            DCN_TRY(dcn_table_reserve(idx, idx->n_keys + n_valid));
+            DCN_TRY(dcn_table_insert_dump(idx, c->d_dump_hash, c->d_dump_valid, c->d_dump_pos, nb, c->d_ascii,
+                                          entropy_threshold, st));
+            p_src.clear();
+            p_len.clear();
+            return DCN_OK;
+        };
+        uint64_t used = 0;
+        for (uint32_t sidx = 0; sidx < n_seqs; ++sidx) {
+            if (offsets[sidx + 1] < offsets[sidx]) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
+            const uint8_t *seq = bases + offsets[sidx];
+            uint64_t len = offsets[sidx + 1] - offsets[sidx];
+            if (len < k || len < l) continue; // src/minimizers.rs:135; fewer than l bases have no window
+            uint64_t a = 0;
+            while (a + l <= len) {
+                uint64_t room = chunk_bases - used;
+                if (room < l || p_len.size() >= max_pieces) {
+                    DCN_TRY(run_chunk());
+                    used = 0;
+                    room = chunk_bases;
+                }
+                uint64_t take = std::min<uint64_t>(room, len - a);
+                if (take > 0xFFFFFF00ull) take = 0xFFFFFF00ull;
+                p_src.push_back(seq + a);
+                p_len.push_back(take);
+                used += take;
+                if (a + take >= len) break;
+                a += take - (l - 1); // next piece starts l-1 bases before the cut
+            }
+        }
+        return run_chunk();
+    };
+    rc = body();
+    dcn_ctx_destroy(c);
     return rc;
 }

@@ -126,17 +126,24 @@ struct dcn_scan_args {
     uint32_t *dump_pos;
     uint8_t *dump_valid;
     uint32_t *dump_count; // per tile
+    uint32_t dump_abs;    // 1: dump_pos holds the low 32 bits of the absolute base index instead of the read position
 };
 
 // ---- kernels launched by api.hip -------------------------------------------------------------------
 int dcn_launch_pack(const uint8_t *d_ascii, uint64_t n_bases, uint32_t *d_packed, uint32_t *d_invmask,
-                    hipStream_t stream);
+                    hipStream_t stream, bool index_side = false);
 int dcn_launch_scan(const dcn_scan_args &args, uint32_t max_tiles, bool dump, hipStream_t stream);
 
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);
 int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t n, uint8_t *out);
 int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
                               hipStream_t stream);
+int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity);                 // empty table for >= that many keys
+int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity);               // grow + rehash if needed
+int dcn_table_insert_dump(dcn_index *idx, const uint64_t *d_hash, const uint8_t *d_valid, const uint32_t *d_abs_pos,
+                          uint64_t n_slots, const uint8_t *d_ascii, float entropy_threshold, hipStream_t stream);
+int dcn_table_count_valid(const uint8_t *d_valid, uint64_t n, uint64_t *count, hipStream_t stream);
+int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity, uint64_t *n_out);
 
 // exclusive prefix sum of n u32 values into out[0..n] (out[n] = total); tmp holds ceil(n/1024)+1 words
 int dcn_launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *d_tmp,

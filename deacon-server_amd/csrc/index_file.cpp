@@ -99,3 +99,45 @@ int dcn_read_index_file(const char *path, uint8_t *k, uint8_t *w, std::vector<ui
     fclose(f);
     return rc;
 }
+
+// write_minimizers (src/index.rs:130-164): header, count, then every hash as a bincode varint
+int dcn_write_index_file(const char *path, uint8_t k, uint8_t w, const uint64_t *keys, uint64_t n) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return dcn_fail(DCN_ERR_IO, std::string("Failed to create output file ") + path);
+    std::vector<uint8_t> buf;
+    buf.reserve(1 << 22);
+    auto put_varint = [&](uint64_t v) {
+        if (v < 251) {
+            buf.push_back((uint8_t)v);
+            return;
+        }
+        size_t nb;
+        if (v <= 0xFFFFull) {
+            buf.push_back(0xFB);
+            nb = 2;
+        } else if (v <= 0xFFFFFFFFull) {
+            buf.push_back(0xFC);
+            nb = 4;
+        } else {
+            buf.push_back(0xFD);
+            nb = 8;
+        }
+        for (size_t i = 0; i < nb; ++i) buf.push_back((uint8_t)(v >> (8 * i)));
+    };
+    buf.push_back(2);
+    buf.push_back(k);
+    buf.push_back(w);
+    put_varint(n);
+    int rc = DCN_OK;
+    for (uint64_t i = 0; i < n && rc == DCN_OK; ++i) {
+        put_varint(keys[i]);
+        if (buf.size() >= (1u << 22) - 16) {
+            if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) rc = dcn_fail(DCN_ERR_IO, "short write");
+            buf.clear();
+        }
+    }
+    if (rc == DCN_OK && !buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size())
+        rc = dcn_fail(DCN_ERR_IO, "short write");
+    if (fclose(f) != 0 && rc == DCN_OK) rc = dcn_fail(DCN_ERR_IO, "close failed");
+    return rc;
+}

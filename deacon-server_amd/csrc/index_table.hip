@@ -136,3 +136,226 @@ int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------
+// index build support (f1 of SURVEY.md 8f): growable table, insertion of dumped minimizer hashes with the
+// index-side filters (src/minimizers.rs:151-168), key export (src/index.rs:130-164 iterates the set)
+// ----------------------------------------------------------------------------------------------------
+namespace {
+
+// p * log2(p) for p = count/total, computed on the HOST in f32 exactly as calculate_scaled_entropy does
+// (src/minimizers.rs:110-116), so the device only subtracts table entries in the reference's order
+constexpr int ENT_MAX = 57;
+__device__ float g_plogp[ENT_MAX][ENT_MAX];
+
+__device__ inline float scaled_entropy_dev(const uint8_t *kmer, uint32_t k) { // src/minimizers.rs:73-121
+    if (k < 10) return 1.0f;
+    uint32_t cnt[4] = {0, 0, 0, 0};
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        uint32_t c = kmer[i] | 0x20u;
+        int j = c == 'a' ? 0 : c == 'c' ? 1 : c == 'g' ? 2 : c == 't' ? 3 : -1;
+        if (j >= 0) {
+            cnt[j]++;
+            total++;
+        }
+    }
+    if (total == 0) return 1.0f;
+    float entropy = 0.0f;
+    for (int j = 0; j < 4; ++j)
+        if (cnt[j] > 0) entropy = __fsub_rn(entropy, g_plogp[total][cnt[j]]);
+    return __fdiv_rn(entropy, 2.0f);
+}
+
+__global__ void insert_dump_kernel(uint64_t *slots, uint32_t group_shift, uint32_t group_mask, const uint64_t *hash,
+                                   const uint8_t *valid, const uint32_t *abs_pos, uint64_t n, const uint8_t *ascii,
+                                   uint32_t k, float entropy_threshold, unsigned long long *n_new, uint32_t *has_zero) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long fresh = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (valid[i] != 1) continue;
+        if (entropy_threshold != 0.0f && scaled_entropy_dev(ascii + abs_pos[i], k) < entropy_threshold) continue;
+        uint64_t key = hash[i];
+        if (key == 0) {
+            if (atomicExch(has_zero, 1u) == 0u) fresh++;
+            continue;
+        }
+        uint32_t g = dcn_group_of(key, group_shift, group_mask);
+        bool done = false;
+        while (!done) {
+            unsigned long long *grp = (unsigned long long *)(slots + (uint64_t)g * DCN_GROUP_SLOTS);
+            for (int s = 0; s < DCN_GROUP_SLOTS && !done; ++s) {
+                unsigned long long cur = __hip_atomic_load(&grp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == key) {
+                    done = true;
+                } else if (cur == 0) {
+                    unsigned long long old = atomicCAS(&grp[s], 0ull, (unsigned long long)key);
+                    if (old == 0) {
+                        fresh++;
+                        done = true;
+                    } else if (old == key) {
+                        done = true;
+                    }
+                }
+            }
+            g = (g + 1) & group_mask;
+        }
+    }
+    if (fresh) atomicAdd(n_new, fresh);
+}
+
+__global__ void count_valid_kernel(const uint8_t *valid, uint64_t n, unsigned long long *count) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) c += valid[i] == 1;
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+__global__ void export_keys_kernel(const uint64_t *slots, uint64_t n_slots, uint64_t *out, uint64_t capacity,
+                                   unsigned long long *cursor) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
+        uint64_t key = slots[i];
+        if (key) {
+            unsigned long long at = atomicAdd(cursor, 1ull);
+            if (at < capacity) out[at] = key;
+        }
+    }
+}
+
+uint64_t groups_for(uint64_t n_keys) {
+    uint64_t groups = 64;
+    while (groups * DCN_GROUP_SLOTS < n_keys * DCN_SLOTS_PER_KEY + 8) groups <<= 1;
+    return groups;
+}
+
+} // namespace
+
+int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity) {
+    DCN_HIP(hipSetDevice(idx->device));
+    uint64_t groups = groups_for(n_keys_capacity);
+    if (groups > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
+    idx->n_groups = groups;
+    DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    DCN_HIP(hipMemset(idx->d_slots, 0, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    idx->n_keys = 0;
+    idx->has_zero = false;
+    return DCN_OK;
+}
+
+// make room for n_keys_capacity keys: allocate a larger table and re-insert every stored key
+int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity) {
+    DCN_HIP(hipSetDevice(idx->device));
+    uint64_t want = groups_for(n_keys_capacity);
+    if (want <= idx->n_groups) return DCN_OK;
+    if (want > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
+    uint64_t *old_slots = idx->d_slots;
+    uint64_t old_n = idx->n_groups * DCN_GROUP_SLOTS;
+    uint64_t keep_keys = idx->n_keys;
+    bool keep_zero = idx->has_zero;
+    idx->d_slots = nullptr;
+    idx->n_groups = want;
+    DCN_HIP(hipMalloc((void **)&idx->d_slots, want * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    DCN_HIP(hipMemset(idx->d_slots, 0, want * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    unsigned long long *d_new = nullptr;
+    uint32_t *d_zero = nullptr;
+    DCN_HIP(hipMalloc((void **)&d_new, sizeof(unsigned long long)));
+    DCN_HIP(hipMalloc((void **)&d_zero, sizeof(uint32_t)));
+    DCN_HIP(hipMemset(d_new, 0, sizeof(unsigned long long)));
+    DCN_HIP(hipMemset(d_zero, 0, sizeof(uint32_t)));
+    dcn_table_view v = idx->view();
+    // the old slot array is a key list with holes: zero entries are skipped by the insert kernel's key==0 branch
+    // only if flagged, so feed it through the plain insert kernel and ignore its zero flag
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((old_n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(table_insert_kernel, dim3(blocks), dim3(256), 0, 0, idx->d_slots, v.group_shift, v.group_mask,
+                       old_slots, old_n, d_new, d_zero);
+    hipError_t e = hipDeviceSynchronize();
+    hipFree(old_slots);
+    hipFree(d_new);
+    hipFree(d_zero);
+    if (e != hipSuccess) return dcn_fail(DCN_ERR_HIP, std::string("table rehash: ") + hipGetErrorString(e));
+    idx->n_keys = keep_keys;
+    idx->has_zero = keep_zero;
+    return DCN_OK;
+}
+
+int dcn_table_count_valid(const uint8_t *d_valid, uint64_t n, uint64_t *count, hipStream_t stream) {
+    unsigned long long *d_c = nullptr;
+    DCN_HIP(hipMalloc((void **)&d_c, sizeof(unsigned long long)));
+    DCN_HIP(hipMemsetAsync(d_c, 0, sizeof(unsigned long long), stream));
+    if (n) {
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(count_valid_kernel, dim3(blocks), dim3(256), 0, stream, d_valid, n, d_c);
+    }
+    unsigned long long h = 0;
+    hipError_t e = hipMemcpyAsync(&h, d_c, sizeof(h), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(d_c);
+    if (e != hipSuccess) return dcn_fail(DCN_ERR_HIP, std::string("count valid: ") + hipGetErrorString(e));
+    *count = h;
+    return DCN_OK;
+}
+
+int dcn_table_insert_dump(dcn_index *idx, const uint64_t *d_hash, const uint8_t *d_valid, const uint32_t *d_abs_pos,
+                          uint64_t n_slots, const uint8_t *d_ascii, float entropy_threshold, hipStream_t stream) {
+    if (n_slots == 0) return DCN_OK;
+    static bool table_ready = false; // the p*log2(p) table is the same for every build
+    if (entropy_threshold != 0.0f && !table_ready) {
+        static float host_tab[ENT_MAX][ENT_MAX];
+        for (int t = 1; t < ENT_MAX; ++t)
+            for (int c = 1; c <= t; ++c) {
+                float p = (float)c / (float)t;
+                host_tab[t][c] = p * log2f(p);
+            }
+        DCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_plogp), host_tab, sizeof(host_tab)));
+        table_ready = true;
+    }
+    unsigned long long *d_new = nullptr;
+    uint32_t *d_zero = nullptr;
+    DCN_HIP(hipMalloc((void **)&d_new, sizeof(unsigned long long)));
+    DCN_HIP(hipMalloc((void **)&d_zero, sizeof(uint32_t)));
+    DCN_HIP(hipMemsetAsync(d_new, 0, sizeof(unsigned long long), stream));
+    DCN_HIP(hipMemsetAsync(d_zero, 0, sizeof(uint32_t), stream));
+    dcn_table_view v = idx->view();
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n_slots + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(insert_dump_kernel, dim3(blocks), dim3(256), 0, stream, idx->d_slots, v.group_shift, v.group_mask,
+                       d_hash, d_valid, d_abs_pos, n_slots, d_ascii, (uint32_t)idx->k, entropy_threshold, d_new, d_zero);
+    unsigned long long h_new = 0;
+    uint32_t h_zero = 0;
+    hipError_t e = hipMemcpyAsync(&h_new, d_new, sizeof(h_new), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_zero, d_zero, sizeof(h_zero), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(d_new);
+    hipFree(d_zero);
+    if (e != hipSuccess) return dcn_fail(DCN_ERR_HIP, std::string("insert dump: ") + hipGetErrorString(e));
+    // the kernel counts the zero key once per call: not new if an earlier chunk already had it
+    idx->n_keys += h_new - ((h_zero && idx->has_zero) ? 1 : 0);
+    idx->has_zero = idx->has_zero || h_zero != 0;
+    return DCN_OK;
+}
+
+int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity, uint64_t *n_out) {
+    DCN_HIP(hipSetDevice(idx->device));
+    *n_out = idx->n_keys;
+    if (capacity < idx->n_keys) return dcn_fail(DCN_ERR_CAPACITY, "output capacity too small: need " + std::to_string(idx->n_keys));
+    uint64_t n_nonzero = idx->n_keys - (idx->has_zero ? 1 : 0);
+    uint64_t at = 0;
+    if (idx->has_zero) host_out[at++] = 0;
+    if (n_nonzero == 0) return DCN_OK;
+    uint64_t *d_out = nullptr;
+    unsigned long long *d_cur = nullptr;
+    DCN_HIP(hipMalloc((void **)&d_out, n_nonzero * sizeof(uint64_t)));
+    hipError_t e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(d_cur, 0, sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        uint64_t n_slots = idx->n_groups * DCN_GROUP_SLOTS;
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((n_slots + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL(export_keys_kernel, dim3(blocks), dim3(256), 0, 0, idx->d_slots, n_slots, d_out, n_nonzero, d_cur);
+        e = hipMemcpy(host_out + at, d_out, n_nonzero * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    }
+    hipFree(d_out);
+    if (d_cur) hipFree(d_cur);
+    if (e != hipSuccess) return dcn_fail(DCN_ERR_HIP, std::string("export keys: ") + hipGetErrorString(e));
+    return DCN_OK;
+}

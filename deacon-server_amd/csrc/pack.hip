@@ -17,6 +17,23 @@ __device__ inline uint32_t pack4(uint32_t x) {
     return (y * ((1u << 24) | (1u << 18) | (1u << 12) | (1u << 6))) >> 24;
 }
 
+// index-side code (src/minimizers.rs:24-43 canonicalise_nucleotide, then the same (c >> 1) & 3):
+// A,W -> A=0; T -> T=2; G,R,S,K,D,V -> G=3; everything else (C,Y,M,B,H,N,...) -> C=1; case-insensitive
+__device__ inline uint32_t pack4_index_side(uint32_t x) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // (byte | 0x20) == 'a' holds exactly for 'A' and 'a' (same for every letter)
+        uint32_t c = ((x >> (8 * j)) & 0xFFu) | 0x20u;
+        bool is_a = (c == 'a') | (c == 'w');
+        bool is_t = (c == 't');
+        bool is_g = (c == 'g') | (c == 'r') | (c == 's') | (c == 'k') | (c == 'd') | (c == 'v');
+        uint32_t code = is_a ? 0u : is_t ? 2u : is_g ? 3u : 1u;
+        out |= code << (2 * j);
+    }
+    return out;
+}
+
 __device__ inline uint32_t invalid4(uint32_t x) {
     // 4 ASCII bytes -> 4 bits, bit j = byte j is not in ACGTacgt
     uint32_t m = 0;
@@ -30,7 +47,7 @@ __device__ inline uint32_t invalid4(uint32_t x) {
 }
 
 // each thread packs 32 bases: two packed words and one mask word
-template <bool ALIGNED>
+template <bool ALIGNED, bool INDEX_SIDE>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, uint64_t n_bases,
                                                    uint32_t *__restrict__ packed,
                                                    uint32_t *__restrict__ invmask, uint64_t n_chunks) {
@@ -60,8 +77,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         uint32_t p0 = 0, p1 = 0, m = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            p0 |= pack4(w[q]) << (8 * q);
-            p1 |= pack4(w[q + 4]) << (8 * q);
+            p0 |= (INDEX_SIDE ? pack4_index_side(w[q]) : pack4(w[q])) << (8 * q);
+            p1 |= (INDEX_SIDE ? pack4_index_side(w[q + 4]) : pack4(w[q + 4])) << (8 * q);
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) m |= invalid4(w[q]) << (4 * q);
@@ -74,18 +91,22 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
 } // namespace
 
 int dcn_launch_pack(const uint8_t *d_ascii, uint64_t n_bases, uint32_t *d_packed, uint32_t *d_invmask,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool index_side) {
     uint64_t n_chunks = (n_bases + 31) / 32;
     if (n_chunks == 0) return DCN_OK;
     uint32_t blocks = (uint32_t)((n_chunks + 255) / 256);
     if (blocks > 256 * 32) blocks = 256 * 32;
     bool aligned = (reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0;
-    if (aligned)
-        hipLaunchKernelGGL(pack_kernel<true>, dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed,
-                           d_invmask, n_chunks);
-    else
-        hipLaunchKernelGGL(pack_kernel<false>, dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed,
-                           d_invmask, n_chunks);
+#define DCN_PACK(AL, IX) \
+    hipLaunchKernelGGL((pack_kernel<AL, IX>), dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed, d_invmask, n_chunks)
+    if (index_side) {
+        if (aligned) DCN_PACK(true, true);
+        else DCN_PACK(false, true);
+    } else {
+        if (aligned) DCN_PACK(true, false);
+        else DCN_PACK(false, false);
+    }
+#undef DCN_PACK
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }

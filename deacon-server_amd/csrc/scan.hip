@@ -269,7 +269,7 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                     if (act[u]) {
                         uint64_t slot = (uint64_t)o_s + o_carry + o_eb + idx[u];
                         a.dump_hash[slot] = valid[u] ? hash[u] : 0;
-                        a.dump_pos[slot] = o_rp + rel[u];
+                        a.dump_pos[slot] = a.dump_abs ? (uint32_t)p[u] : o_rp + rel[u];
                         a.dump_valid[slot] = valid[u] ? 1 : 0;
                     }
                 }

@@ -71,6 +71,27 @@ class Index:
         N.check(N.lib().dcn_index_from_file(os.fsencode(path), device, C.byref(h)))
         return cls(h, device)
 
+    @classmethod
+    def build(cls, seqs, kmer_length=DEFAULT_KMER_LENGTH, window_size=DEFAULT_WINDOW_SIZE, entropy_threshold=0.0,
+              capacity_keys=0, device=0):
+        """index::build (index.rs:167-308) for sequences in memory: index-side minimizers merged on the device."""
+        bases, offsets = concat_reads(seqs)
+        h = C.c_void_p()
+        N.check(N.lib().dcn_index_build(_ptr(bases) if len(bases) else None, _ptr(offsets), len(seqs), kmer_length,
+                                        window_size, float(entropy_threshold), int(capacity_keys), device, C.byref(h)))
+        return cls(h, device)
+
+    def keys(self):
+        """The distinct minimizer hashes (arbitrary order, like iterating the reference's set)."""
+        out = np.zeros(max(self.n_keys, 1), np.uint64)
+        n = C.c_uint64()
+        N.check(N.lib().dcn_index_keys(self._h, _ptr(out), len(out), C.byref(n)))
+        return out[:n.value]
+
+    def write(self, path):
+        """index::write_minimizers (index.rs:130-164): the reference's index file format."""
+        N.check(N.lib().dcn_index_write_file(self._h, os.fsencode(path)))
+
     def header(self):
         return self.kmer_length, self.window_size, self.n_keys
 

@@ -78,6 +78,23 @@ int dcn_index_from_keys(const uint64_t *keys, uint64_t n, uint8_t k, uint8_t w, 
  * src/index.rs:130-164; header validation as IndexHeader::validate, src/index.rs:34-43). */
 int dcn_index_from_file(const char *path, int device, dcn_index **out);
 
+/* Build the index from sequences held in host memory: index::build (src/index.rs:167-308) minus FASTX parsing.
+ * Every sequence goes through the index-side rule (minimizers::fill_minimizer_hashes, src/minimizers.rs:125-191:
+ * IUPAC codes canonicalised to ACGT before the scan, minimizers whose k-mer has a non-ACGT base in the ORIGINAL
+ * bytes dropped, optional scaled-entropy floor) and the hashes are merged into one device set.
+ *   bases / offsets   concatenated sequences and n_seqs+1 byte offsets, as for dcn_filter_batch
+ *   entropy_threshold 0 = off (the reference's default, src/lib.rs:224)
+ *   capacity_keys     pre-allocation hint (IndexConfig::capacity_millions, src/lib.rs:200); 0 = grow as needed */
+int dcn_index_build(const uint8_t *bases, const uint64_t *offsets, uint32_t n_seqs, uint8_t k, uint8_t w,
+                    float entropy_threshold, uint64_t capacity_keys, int device, dcn_index **out);
+
+/* Copy the distinct keys to host memory in arbitrary order (the reference iterates its FxHashSet, src/index.rs:159);
+ * *n receives the key count; DCN_ERR_CAPACITY if capacity is smaller. */
+int dcn_index_keys(const dcn_index *index, uint64_t *out, uint64_t capacity, uint64_t *n);
+
+/* Write the index in the reference's file format: write_minimizers (src/index.rs:130-164). */
+int dcn_index_write_file(const dcn_index *index, const char *path);
+
 /* Header fields and the number of DISTINCT keys (what `deacon index info` prints, src/index.rs:539-560). */
 int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n_keys);
 

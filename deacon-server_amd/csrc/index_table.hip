@@ -12,6 +12,8 @@
 
 namespace {
 
+// SKIP_ZERO: `keys` is an old slot array (0 = empty slot, not a key) being re-inserted into a larger table
+template <bool SKIP_ZERO>
 __global__ void table_insert_kernel(uint64_t *slots, uint32_t group_shift, uint32_t group_mask,
                                     const uint64_t *keys, uint64_t n, unsigned long long *n_new,
                                     uint32_t *has_zero) {
@@ -20,7 +22,7 @@ __global__ void table_insert_kernel(uint64_t *slots, uint32_t group_shift, uint3
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         uint64_t key = keys[i];
         if (key == 0) {
-            if (atomicExch(has_zero, 1u) == 0u) fresh++;
+            if (!SKIP_ZERO && atomicExch(has_zero, 1u) == 0u) fresh++;
             continue;
         }
         uint32_t g = dcn_group_of(key, group_shift, group_mask);
@@ -84,7 +86,7 @@ int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n) {
             break;
         }
         uint32_t blocks = (uint32_t)std::min<uint64_t>((m + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL(table_insert_kernel, dim3(blocks), dim3(256), 0, 0, idx->d_slots, v.group_shift,
+        hipLaunchKernelGGL(table_insert_kernel<false>, dim3(blocks), dim3(256), 0, 0, idx->d_slots, v.group_shift,
                            v.group_mask, d_keys, m, d_new, d_zero);
         e = hipDeviceSynchronize();
         if (e != hipSuccess) rc = dcn_fail(DCN_ERR_HIP, std::string("table insert: ") + hipGetErrorString(e));
@@ -215,10 +217,18 @@ __global__ void count_valid_kernel(const uint8_t *valid, uint64_t n, unsigned lo
 __global__ void export_keys_kernel(const uint64_t *slots, uint64_t n_slots, uint64_t *out, uint64_t capacity,
                                    unsigned long long *cursor) {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += stride) {
-        uint64_t key = slots[i];
+    const int lane = threadIdx.x & 63;
+    // whole waves iterate together: one cursor atomic per wave and iteration
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < n_slots; i0 += stride) {
+        uint64_t i = i0 + lane;
+        uint64_t key = i < n_slots ? slots[i] : 0;
+        unsigned long long m = __ballot(key != 0);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0, 64);
         if (key) {
-            unsigned long long at = atomicAdd(cursor, 1ull);
+            unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1));
             if (at < capacity) out[at] = key;
         }
     }
@@ -265,10 +275,9 @@ int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity) {
     DCN_HIP(hipMemset(d_new, 0, sizeof(unsigned long long)));
     DCN_HIP(hipMemset(d_zero, 0, sizeof(uint32_t)));
     dcn_table_view v = idx->view();
-    // the old slot array is a key list with holes: zero entries are skipped by the insert kernel's key==0 branch
-    // only if flagged, so feed it through the plain insert kernel and ignore its zero flag
+    // the old slot array is a key list with holes (0 = empty slot)
     uint32_t blocks = (uint32_t)std::min<uint64_t>((old_n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(table_insert_kernel, dim3(blocks), dim3(256), 0, 0, idx->d_slots, v.group_shift, v.group_mask,
+    hipLaunchKernelGGL(table_insert_kernel<true>, dim3(blocks), dim3(256), 0, 0, idx->d_slots, v.group_shift, v.group_mask,
                        old_slots, old_n, d_new, d_zero);
     hipError_t e = hipDeviceSynchronize();
     hipFree(old_slots);

@@ -29,30 +29,51 @@ __global__ __launch_bounds__(256) void plan_reads_kernel(dcn_plan_args a) {
     }
 }
 
+__device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32_t j, uint64_t off, uint32_t nwin,
+                                  uint32_t unit) {
+    uint32_t wstart = j * a.tile_windows;
+    uint32_t carry = j > 0 ? 1u : 0u;
+    dcn_tile t;
+    t.scan_start = off + wstart - carry;
+    t.read_pos = wstart - carry;
+    t.unit = unit;
+    t.n_windows = min(a.tile_windows, nwin - wstart);
+    t.flags = carry;
+    a.tiles[first + j] = t;
+}
+
 __global__ __launch_bounds__(256) void plan_tiles_kernel(dcn_plan_args a) {
+    // a thread writes the first few tiles of its read; reads with more tiles (long reads, chromosomes during an
+    // index build) are finished by the whole workgroup in a block-stride loop
+    constexpr uint32_t OWN = 4;
+    __shared__ uint32_t long_reads[256];
+    __shared__ uint32_t n_long;
+    if (threadIdx.x == 0) n_long = 0;
+    __syncthreads();
     uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
-    uint32_t first = a.read_tile_first[r], nt = a.read_tile_first[r + 1] - first;
-    uint32_t u = a.unit_id ? a.unit_id[r] : r;
-    bool unit_head = a.unit_id ? (r == 0 || a.unit_id[r - 1] != u) : true;
-    if (unit_head) a.unit_tile_first[u] = first;
-    if (r == a.n_reads - 1) {
-        uint32_t total = a.read_tile_first[a.n_reads];
-        a.unit_tile_first[a.n_units] = total;
-        a.status->n_tiles = total;
+    if (r < a.n_reads) {
+        uint32_t first = a.read_tile_first[r], nt = a.read_tile_first[r + 1] - first;
+        uint32_t u = a.unit_id ? a.unit_id[r] : r;
+        bool unit_head = a.unit_id ? (r == 0 || a.unit_id[r - 1] != u) : true;
+        if (unit_head) a.unit_tile_first[u] = first;
+        if (r == a.n_reads - 1) {
+            uint32_t total = a.read_tile_first[a.n_reads];
+            a.unit_tile_first[a.n_units] = total;
+            a.status->n_tiles = total;
+        }
+        uint32_t nwin = a.read_windows[r];
+        uint64_t off = a.offsets[r];
+        for (uint32_t j = 0; j < min(nt, OWN); ++j) write_tile(a, first, j, off, nwin, u);
+        if (nt > OWN) long_reads[atomicAdd(&n_long, 1u)] = r;
     }
-    uint32_t nwin = a.read_windows[r];
-    uint64_t off = a.offsets[r];
-    for (uint32_t j = 0; j < nt; ++j) {
-        uint32_t wstart = j * a.tile_windows;
-        uint32_t carry = j > 0 ? 1u : 0u;
-        dcn_tile t;
-        t.scan_start = off + wstart - carry;
-        t.read_pos = wstart - carry;
-        t.unit = u;
-        t.n_windows = min(a.tile_windows, nwin - wstart);
-        t.flags = carry;
-        a.tiles[first + j] = t;
+    __syncthreads();
+    for (uint32_t q = 0; q < n_long; ++q) {
+        uint32_t lr = long_reads[q];
+        uint32_t first = a.read_tile_first[lr], nt = a.read_tile_first[lr + 1] - first;
+        uint32_t u = a.unit_id ? a.unit_id[lr] : lr;
+        uint32_t nwin = a.read_windows[lr];
+        uint64_t off = a.offsets[lr];
+        for (uint32_t j = OWN + threadIdx.x; j < nt; j += blockDim.x) write_tile(a, first, j, off, nwin, u);
     }
 }
 

@@ -1,0 +1,614 @@
+// deacon-hip -- command-line driver around libdeacon_hip.so with the reference's `deacon` surface for the path this
+// repository accelerates:
+//
+//   deacon-hip index build <fastx> [-k 31] [-w 15] [-o out.idx] [-c capacity_millions] [-e entropy] [-q]
+//   deacon-hip index info  <index>
+//   deacon-hip filter <index> [input|-] [input2|-] [-o out] [-O out2] [-a 2] [-r 0.01] [-p 0] [-d] [-R]
+//                     [-s summary.json] [-t threads] [--compression-level 2] [--debug] [-q]
+//
+// Flags, defaults, stderr messages and the JSON summary follow src/main.rs:24-234, src/local_filter.rs:575-824 and
+// src/filter_common.rs:11-38 of the reference.  The per-record loop of local_filter.rs (paraseq workers calling
+// should_keep_sequence / should_keep_pair) is replaced by batches through dcn_filter_batch: a reader thread parses
+// FASTA/FASTQ (plain or gzip) into batches, the main thread runs them on the GPU, a writer thread formats the kept
+// records (format_record_to_buffer, src/local_filter.rs:60-92).  Output keeps the input order (the reference's
+// order depends on worker scheduling).  `index union/diff` and the server/client commands are not part of this path.
+// Input/output compression: gzip via zlib; zstd and xz are not available in this build.
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "deacon_hip.hpp"
+
+namespace {
+
+const char *VERSION = "0.1.0";
+
+[[noreturn]] void die(const std::string &msg) {
+    std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    std::exit(1);
+}
+
+bool ends_with(const std::string &s, const char *suf) {
+    size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+// ---- input: plain or gzip, file or stdin (niffler's role in src/local_filter.rs:41-55) -------------------------
+class Input {
+  public:
+    explicit Input(const std::string &path) {
+        if (path == "-") gz_ = gzdopen(0, "rb");
+        else gz_ = gzopen(path.c_str(), "rb");  // zlib reads plain files transparently
+        if (!gz_) die("Failed to open file " + path);
+        gzbuffer(gz_, 1 << 20);
+    }
+    ~Input() {
+        if (gz_) gzclose(gz_);
+    }
+    size_t read(char *dst, size_t n) {
+        size_t got = 0;
+        while (got < n) {
+            int r = gzread(gz_, dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+            if (r < 0) die("read error");
+            if (r == 0) break;
+            got += (size_t)r;
+        }
+        return got;
+    }
+
+  private:
+    gzFile gz_ = nullptr;
+};
+
+// ---- output: plain or gzip (get_writer, src/local_filter.rs:110-151) ------------------------------------------
+class Output {
+  public:
+    Output(const std::string &path, int level) {
+        if (ends_with(path, ".zst") || ends_with(path, ".xz")) die("zstd / xz output is not available in this build: " + path);
+        if (ends_with(path, ".gz")) {
+            if (level < 1 || level > 9) die("Invalid gzip compression level " + std::to_string(level) + ". Must be between 1 and 9.");
+            std::string mode = "wb" + std::to_string(level);
+            gz_ = gzopen(path.c_str(), mode.c_str());
+            if (!gz_) die("Failed to create output file: " + path);
+            gzbuffer(gz_, 1 << 20);
+        } else if (path == "-") {
+            f_ = stdout;
+        } else {
+            f_ = std::fopen(path.c_str(), "wb");
+            if (!f_) die("Failed to create output file: " + path);
+            own_ = true;
+        }
+        if (f_) std::setvbuf(f_, nullptr, _IOFBF, 8 << 20);  // OUTPUT_BUFFER_SIZE
+    }
+    ~Output() { close(); }
+    void write(const std::vector<char> &buf) {
+        if (buf.empty()) return;
+        if (gz_) {
+            if (gzwrite(gz_, buf.data(), (unsigned)buf.size()) != (int)buf.size()) die("write error");
+        } else if (std::fwrite(buf.data(), 1, buf.size(), f_) != buf.size()) {
+            die("write error");
+        }
+    }
+    void close() {
+        if (gz_) gzclose(gz_);
+        gz_ = nullptr;
+        if (f_) {
+            std::fflush(f_);
+            if (own_) std::fclose(f_);
+        }
+        f_ = nullptr;
+    }
+
+  private:
+    gzFile gz_ = nullptr;
+    FILE *f_ = nullptr;
+    bool own_ = false;
+};
+
+// ---- FASTA / FASTQ records -------------------------------------------------------------------------------------
+struct Rec {
+    uint32_t id_off, id_len;  // header line without the leading '>' / '@', in Batch::text
+    uint64_t seq_off;         // newline-free sequence in Batch::bases
+    uint32_t seq_len;
+    uint32_t qual_off;        // in Batch::text; UINT32_MAX for FASTA
+};
+
+struct Batch {
+    uint64_t seq_no = 0;
+    std::vector<char> text;      // ids and qualities
+    std::vector<uint8_t> bases;  // concatenated sequences (what dcn_filter_batch takes)
+    std::vector<uint64_t> offsets{0};
+    std::vector<uint32_t> unit_id;
+    std::vector<Rec> recs;
+    std::vector<uint8_t> keep;
+    std::vector<uint32_t> hits, total;
+    bool paired = false;
+    void clear() {
+        text.clear();
+        bases.clear();
+        offsets.assign(1, 0);
+        unit_id.clear();
+        recs.clear();
+    }
+};
+
+// streaming parser over a refillable window; one record at a time, appended to a Batch
+class FastxReader {
+  public:
+    explicit FastxReader(const std::string &path) : in_(path), buf_(1 << 24) {}
+
+    // appends the next record to b; false at end of input
+    bool next(Batch &b) {
+        std::string_view line;
+        do {
+            if (!getline(line)) return false;
+        } while (line.empty());
+        char marker = line[0];
+        if (marker != '>' && marker != '@') die("Invalid FASTX record start: expected '>' or '@'");
+        Rec r;
+        r.id_off = (uint32_t)b.text.size();
+        r.id_len = (uint32_t)line.size() - 1;
+        b.text.insert(b.text.end(), line.begin() + 1, line.end());
+        r.seq_off = b.bases.size();
+        if (marker == '>') {
+            // FASTA: sequence lines until the next header (multi-line records are joined, src/local_filter.rs:347)
+            while (peek() != '>' && peek() != 0) {
+                if (!getline(line)) break;
+                b.bases.insert(b.bases.end(), line.begin(), line.end());
+            }
+            r.qual_off = UINT32_MAX;
+        } else {
+            if (!getline(line)) die("Truncated FASTQ record");
+            b.bases.insert(b.bases.end(), line.begin(), line.end());
+            if (!getline(line) || line.empty() || line[0] != '+') die("Invalid FASTQ record: missing '+' line");
+            if (!getline(line)) die("Truncated FASTQ record");
+            r.qual_off = (uint32_t)b.text.size();
+            b.text.insert(b.text.end(), line.begin(), line.end());
+            if (line.size() != b.bases.size() - r.seq_off) die("FASTQ sequence and quality lengths differ");
+        }
+        r.seq_len = (uint32_t)(b.bases.size() - r.seq_off);
+        b.recs.push_back(r);
+        b.offsets.push_back(b.bases.size());
+        return true;
+    }
+
+  private:
+    void refill() {
+        if (eof_) return;
+        size_t rem = end_ - pos_;
+        if (pos_ > 0) std::memmove(buf_.data(), buf_.data() + pos_, rem);
+        pos_ = 0;
+        end_ = rem;
+        if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+        size_t got = in_.read(buf_.data() + end_, buf_.size() - end_);
+        end_ += got;
+        if (got == 0) eof_ = true;
+    }
+    char peek() {
+        if (pos_ == end_) refill();
+        return pos_ < end_ ? buf_[pos_] : 0;
+    }
+    bool getline(std::string_view &out) {
+        for (;;) {
+            char *nl = (char *)std::memchr(buf_.data() + pos_, '\n', end_ - pos_);
+            if (nl) {
+                size_t len = nl - (buf_.data() + pos_);
+                out = std::string_view(buf_.data() + pos_, len);
+                pos_ += len + 1;
+                if (!out.empty() && out.back() == '\r') out.remove_suffix(1);
+                return true;
+            }
+            if (eof_) {
+                if (pos_ == end_) return false;
+                out = std::string_view(buf_.data() + pos_, end_ - pos_);
+                pos_ = end_;
+                return true;
+            }
+            refill();
+        }
+    }
+    Input in_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+};
+
+template <typename T>
+class Queue {  // bounded hand-off between the pipeline threads
+  public:
+    explicit Queue(size_t cap) : cap_(cap) {}
+    void push(T v) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        cv_.notify_all();
+    }
+    bool pop(T &out) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return !q_.empty() || done_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        cv_.notify_all();
+        return true;
+    }
+    void finish() {
+        std::lock_guard<std::mutex> l(m_);
+        done_ = true;
+        cv_.notify_all();
+    }
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool done_ = false;
+};
+
+std::string fmt_duration(double s) {  // like Rust's {:.2?} for Duration
+    char b[64];
+    if (s >= 1.0) std::snprintf(b, sizeof b, "%.2fs", s);
+    else if (s >= 1e-3) std::snprintf(b, sizeof b, "%.2fms", s * 1e3);
+    else std::snprintf(b, sizeof b, "%.2fµs", s * 1e6);
+    return b;
+}
+
+std::string json_str(const std::string &s) {
+    std::string o = "\"";
+    for (char c : s) {
+        if (c == '"' || c == '\\') o += '\\';
+        o += c;
+    }
+    return o + "\"";
+}
+
+struct FilterArgs {
+    std::string index, input = "-", output = "-";
+    std::string input2, output2, summary;
+    bool has_input2 = false, has_output2 = false, has_summary = false;
+    unsigned abs_threshold = 2;
+    double rel_threshold = 0.01;
+    size_t prefix_length = 0;
+    bool deplete = false, rename = false, debug = false, quiet = false;
+    size_t threads = 8;
+    int compression_level = 2;
+};
+
+// ---- deacon filter (src/local_filter.rs:575-824) ---------------------------------------------------------------
+int run_filter(const FilterArgs &a) {
+    using clock = std::chrono::steady_clock;
+    auto start = clock::now();
+    bool quiet = a.quiet || a.debug;  // :581
+    bool paired_stdin = a.input == "-" && a.has_input2 && a.input2 == "-";
+    bool paired = a.has_input2;
+    if (!quiet) {
+        std::string opts = "abs_threshold=" + std::to_string(a.abs_threshold) + ", rel_threshold=" + std::to_string(a.rel_threshold);
+        // Rust prints the shortest round-trip form of the f64; trim trailing zeros of the fixed form
+        {
+            char b[64];
+            std::snprintf(b, sizeof b, "%.17g", a.rel_threshold);
+            std::string shortest = b;
+            for (int prec = 1; prec < 17; ++prec) {
+                std::snprintf(b, sizeof b, "%.*g", prec, a.rel_threshold);
+                if (std::strtod(b, nullptr) == a.rel_threshold) {
+                    shortest = b;
+                    break;
+                }
+            }
+            opts = "abs_threshold=" + std::to_string(a.abs_threshold) + ", rel_threshold=" + shortest;
+        }
+        if (a.prefix_length > 0) opts += ", prefix_length=" + std::to_string(a.prefix_length);
+        if (a.rename) opts += ", rename";
+        if (a.threads > 0) opts += ", threads=" + std::to_string(a.threads);
+        std::fprintf(stderr, "Deacon-hip v%s; mode: %s; input: %s; options: %s\n", VERSION, a.deplete ? "deplete" : "search",
+                     paired_stdin ? "interleaved" : paired ? "paired" : "single", opts.c_str());
+    }
+    deacon::Index index = deacon::Index::load(a.index);
+    auto hd = index.header();
+    if (!quiet)
+        std::fprintf(stderr, "Loaded index (k=%u, w=%u) in %s\n", hd.kmer_length, hd.window_size,
+                     fmt_duration(std::chrono::duration<double>(clock::now() - start).count()).c_str());
+    Output out1(a.output, a.compression_level);
+    std::unique_ptr<Output> out2;
+    if (a.has_output2 && paired) out2.reset(new Output(a.output2, a.compression_level));
+    else if (a.has_output2 && !quiet) std::fprintf(stderr, "Warning: --output2 specified but no second input file provided. --output2 will be ignored.\n");
+
+    const uint64_t batch_bases = 1ull << 26;
+    const uint32_t batch_reads = 1u << 20;
+    deacon::FilterConfig cfg;
+    cfg.abs_threshold = a.abs_threshold;
+    cfg.rel_threshold = a.rel_threshold;
+    cfg.prefix_length = a.prefix_length;
+    cfg.deplete = a.deplete;
+    cfg.max_batch_bases = batch_bases + (1 << 24);
+    cfg.max_batch_reads = batch_reads + 2;
+    deacon::FilterProcessor proc(index, cfg);
+
+    Queue<std::unique_ptr<Batch>> parsed(3), filtered(3);
+    // reader thread: parse into batches (pairs are never split across batches)
+    std::thread reader([&] {
+        FastxReader r1(a.input);
+        std::unique_ptr<FastxReader> r2;
+        if (paired && !paired_stdin) r2.reset(new FastxReader(a.input2));
+        uint64_t seq_no = 0;
+        bool more = true;
+        while (more) {
+            std::unique_ptr<Batch> b(new Batch());
+            b->paired = paired;
+            b->seq_no = seq_no++;
+            while (b->bases.size() < batch_bases && b->recs.size() < batch_reads) {
+                if (!r1.next(*b)) {
+                    more = false;
+                    break;
+                }
+                if (paired) {
+                    bool ok = paired_stdin ? r1.next(*b) : r2->next(*b);
+                    if (!ok) die("Paired input ended with an unpaired record");
+                    uint32_t u = (uint32_t)(b->recs.size() / 2 - 1);
+                    b->unit_id.push_back(u);
+                    b->unit_id.push_back(u);
+                }
+            }
+            if (!b->recs.empty()) parsed.push(std::move(b));
+        }
+        if (r2) {
+            Batch extra;
+            if (r2->next(extra)) die("Second input has more records than the first");
+        }
+        parsed.finish();
+    });
+
+    uint64_t total_seqs = 0, filtered_seqs = 0, total_bp = 0, output_bp = 0, filtered_bp = 0, out_counter = 0;
+    // writer thread: format kept records in input order
+    std::thread writer([&] {
+        std::unique_ptr<Batch> b;
+        std::vector<char> buf1, buf2;
+        while (filtered.pop(b)) {
+            buf1.clear();
+            buf2.clear();
+            size_t per_unit = b->paired ? 2 : 1;
+            for (size_t i = 0; i < b->recs.size(); ++i) {
+                const Rec &r = b->recs[i];
+                size_t u = i / per_unit;
+                total_seqs++;
+                total_bp += r.seq_len;
+                if (!b->keep[u]) {
+                    filtered_seqs++;
+                    filtered_bp += r.seq_len;
+                    continue;
+                }
+                output_bp += r.seq_len;
+                out_counter++;
+                std::vector<char> &dst = (out2 && (i & 1)) ? buf2 : buf1;  // mate 2 to --output2
+                bool fasta = r.qual_off == UINT32_MAX;
+                dst.push_back(fasta ? '>' : '@');
+                if (a.rename) {
+                    std::string n = std::to_string(out_counter);
+                    dst.insert(dst.end(), n.begin(), n.end());
+                } else {
+                    dst.insert(dst.end(), b->text.begin() + r.id_off, b->text.begin() + r.id_off + r.id_len);
+                }
+                dst.push_back('\n');
+                dst.insert(dst.end(), b->bases.begin() + r.seq_off, b->bases.begin() + r.seq_off + r.seq_len);
+                if (fasta) {
+                    dst.push_back('\n');
+                } else {
+                    dst.insert(dst.end(), {'\n', '+', '\n'});
+                    dst.insert(dst.end(), b->text.begin() + r.qual_off, b->text.begin() + r.qual_off + r.seq_len);
+                    dst.push_back('\n');
+                }
+            }
+            out1.write(buf1);
+            if (out2) out2->write(buf2);
+        }
+    });
+
+    // GPU stage on the main thread
+    {
+        std::unique_ptr<Batch> b;
+        while (parsed.pop(b)) {
+            size_t n_units = b->paired ? b->recs.size() / 2 : b->recs.size();
+            b->keep.assign(n_units, 0);
+            b->hits.assign(n_units, 0);
+            b->total.assign(n_units, 0);
+            proc.filter_batch(b->bases.data(), b->offsets.data(), b->paired ? b->unit_id.data() : nullptr,
+                              (uint32_t)b->recs.size(), b->keep.data(), b->hits.data(), b->total.data());
+            if (a.debug) {  // src/local_filter.rs:354-363 (the matched k-mer strings are not reproduced)
+                size_t per_unit = b->paired ? 2 : 1;
+                for (size_t u = 0; u < n_units; ++u) {
+                    if (b->paired && b->hits[u] == 0) continue;
+                    const Rec &r = b->recs[u * per_unit];
+                    std::fprintf(stderr, "DEBUG: %.*s hits=%u/%u keep=%s kmers=[]\n", (int)r.id_len, b->text.data() + r.id_off,
+                                 b->hits[u], b->total[u], b->keep[u] ? "true" : "false");
+                }
+            }
+            filtered.push(std::move(b));
+        }
+        filtered.finish();
+    }
+    reader.join();
+    writer.join();
+    out1.close();
+    if (out2) out2->close();
+
+    double secs = std::chrono::duration<double>(clock::now() - start).count();
+    uint64_t seqs_out = total_seqs - filtered_seqs;
+    auto prop = [](uint64_t x, uint64_t y) { return y ? (double)x / (double)y : 0.0; };
+    if (!quiet)
+        std::fprintf(stderr,
+                     "Retained %llu/%llu sequences (%.3f%%), %llu/%llu bp (%.3f%%) in %s. Speed: %.0f seqs/s (%.1f Mbp/s)\n",
+                     (unsigned long long)seqs_out, (unsigned long long)total_seqs, prop(seqs_out, total_seqs) * 100.0,
+                     (unsigned long long)output_bp, (unsigned long long)total_bp, prop(output_bp, total_bp) * 100.0,
+                     fmt_duration(secs).c_str(), total_seqs / secs, total_bp / secs / 1e6);
+    if (a.has_summary) {  // FilterSummary, src/filter_common.rs:11-38
+        FILE *f = std::fopen(a.summary.c_str(), "w");
+        if (!f) die("Failed to create summary: " + a.summary);
+        auto opt = [&](bool has, const std::string &v) { return has ? json_str(v) : std::string("null"); };
+        std::fprintf(f,
+                     "{\n  \"version\": %s,\n  \"index\": %s,\n  \"input\": %s,\n  \"input2\": %s,\n  \"output\": %s,\n"
+                     "  \"output2\": %s,\n  \"k\": %u,\n  \"w\": %u,\n  \"abs_threshold\": %u,\n  \"rel_threshold\": %.17g,\n"
+                     "  \"prefix_length\": %zu,\n  \"deplete\": %s,\n  \"rename\": %s,\n  \"seqs_in\": %llu,\n  \"seqs_out\": %llu,\n"
+                     "  \"seqs_out_proportion\": %.17g,\n  \"seqs_removed\": %llu,\n  \"seqs_removed_proportion\": %.17g,\n"
+                     "  \"bp_in\": %llu,\n  \"bp_out\": %llu,\n  \"bp_out_proportion\": %.17g,\n  \"bp_removed\": %llu,\n"
+                     "  \"bp_removed_proportion\": %.17g,\n  \"time\": %.17g,\n  \"seqs_per_second\": %llu,\n  \"bp_per_second\": %llu\n}",
+                     json_str(std::string("deacon-hip ") + VERSION).c_str(), json_str(a.index).c_str(), json_str(a.input).c_str(),
+                     opt(a.has_input2, a.input2).c_str(), json_str(a.output).c_str(), opt(a.has_output2, a.output2).c_str(),
+                     hd.kmer_length, hd.window_size, a.abs_threshold, a.rel_threshold, a.prefix_length,
+                     a.deplete ? "true" : "false", a.rename ? "true" : "false", (unsigned long long)total_seqs,
+                     (unsigned long long)seqs_out, prop(seqs_out, total_seqs), (unsigned long long)filtered_seqs,
+                     prop(filtered_seqs, total_seqs), (unsigned long long)total_bp, (unsigned long long)output_bp,
+                     prop(output_bp, total_bp), (unsigned long long)filtered_bp, prop(filtered_bp, total_bp), secs,
+                     (unsigned long long)(total_seqs / secs), (unsigned long long)(total_bp / secs));
+        std::fclose(f);
+        if (!quiet) std::fprintf(stderr, "Summary saved to \"%s\"\n", a.summary.c_str());
+    }
+    return 0;
+}
+
+// ---- deacon index build (src/index.rs:167-308) / info (:539-560) ----------------------------------------------
+int run_index_build(const std::string &input, unsigned k, unsigned w, const std::string &output, size_t capacity_millions,
+                    float entropy, bool quiet) {
+    auto start = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "Deacon-hip v%s; mode: build; input: single; options: capacity=%zuM\n", VERSION, capacity_millions);
+    if ((k + w - 1) % 2 == 0)
+        die("Constraint violated: k + w - 1 must be odd (k=" + std::to_string(k) + ", w=" + std::to_string(w) + ")");
+    std::fprintf(stderr, "Building index (k=%u, w=%u)\n", k, w);
+    FastxReader rd(input);
+    Batch all;
+    while (rd.next(all)) {
+        if (!quiet) {
+            const Rec &r = all.recs.back();
+            std::fprintf(stderr, "  %.*s (%ubp)\n", (int)r.id_len, all.text.data() + r.id_off, r.seq_len);
+        }
+    }
+    dcn_index *raw = nullptr;
+    // the capacity flag is only a pre-allocation hint (the table grows as needed); cap it by what the input can hold
+    uint64_t hint = std::min<uint64_t>((uint64_t)capacity_millions * 1000000ull, all.bases.size() / 4 + 1024);
+    deacon::check(dcn_index_build(all.bases.data(), all.offsets.data(), (uint32_t)all.recs.size(), (uint8_t)k, (uint8_t)w,
+                                  entropy, hint, 0, &raw));
+    uint64_t n = 0;
+    deacon::check(dcn_index_header(raw, nullptr, nullptr, &n));
+    std::fprintf(stderr, "Indexed %llu minimizers from %zu sequence(s) (%zubp)\n", (unsigned long long)n, all.recs.size(),
+                 all.bases.size());
+    std::string path = output;
+    if (output == "-") path = "/dev/stdout";
+    int rc = dcn_index_write_file(raw, path.c_str());
+    dcn_index_destroy(raw);
+    deacon::check(rc);
+    std::fprintf(stderr, "Completed in %s\n",
+                 fmt_duration(std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()).c_str());
+    return 0;
+}
+
+int run_index_info(const std::string &path) {
+    auto start = std::chrono::steady_clock::now();
+    deacon::Index idx = deacon::Index::load(path);
+    auto hd = idx.header();
+    std::fprintf(stderr, "Index information:\n  Format version: %u\n  K-mer length (k): %u\n  Window size (w): %u\n"
+                         "  Distinct minimizer count: %llu\n",
+                 hd.format_version, hd.kmer_length, hd.window_size, (unsigned long long)idx.len());
+    std::fprintf(stderr, "Retrieved index info in %s\n",
+                 fmt_duration(std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()).c_str());
+    return 0;
+}
+
+void usage() {
+    std::fprintf(stderr,
+                 "Usage: deacon-hip <COMMAND>\n\nCommands:\n  index   Build and inspect minimizer indexes (build, info)\n"
+                 "  filter  Keep or discard DNA fastx records with sufficient minimizer hits to an index\n\n"
+                 "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::vector<std::string> args(argv + 1, argv + argc);
+    if (args.empty()) {
+        usage();
+        return 2;  // clap exits with 2 when a required subcommand is missing (tests/cli_tests.rs)
+    }
+    try {
+        if (args[0] == "--version" || args[0] == "-V") {
+            std::printf("deacon-hip %s\n", VERSION);
+            return 0;
+        }
+        if (args[0] == "--help" || args[0] == "-h") {
+            usage();
+            return 0;
+        }
+        auto need = [&](size_t i) -> const std::string & {
+            if (i >= args.size()) die("missing value for " + args[i - 1]);
+            return args[i];
+        };
+        if (args[0] == "filter") {
+            FilterArgs a;
+            std::vector<std::string> pos;
+            for (size_t i = 1; i < args.size(); ++i) {
+                const std::string &s = args[i];
+                if (s == "-o" || s == "--output") a.output = need(++i);
+                else if (s == "-O" || s == "--output2") a.output2 = need(++i), a.has_output2 = true;
+                else if (s == "-a" || s == "--abs-threshold") {
+                    long v = std::atol(need(++i).c_str());
+                    if (v < 1 || v > 65535) die("invalid value for --abs-threshold: must be 1..65535");
+                    a.abs_threshold = (unsigned)v;
+                } else if (s == "-r" || s == "--rel-threshold") a.rel_threshold = std::atof(need(++i).c_str());
+                else if (s == "-p" || s == "--prefix-length") a.prefix_length = (size_t)std::atoll(need(++i).c_str());
+                else if (s == "-d" || s == "--deplete") a.deplete = true;
+                else if (s == "-R" || s == "--rename") a.rename = true;
+                else if (s == "-s" || s == "--summary") a.summary = need(++i), a.has_summary = true;
+                else if (s == "-t" || s == "--threads") a.threads = (size_t)std::atoll(need(++i).c_str());
+                else if (s == "--compression-level") a.compression_level = std::atoi(need(++i).c_str());
+                else if (s == "--debug") a.debug = true;
+                else if (s == "-q" || s == "--quiet") a.quiet = true;
+                else if (s.size() > 1 && s[0] == '-' && s != "-") die("unexpected argument '" + s + "'");
+                else pos.push_back(s);
+            }
+            if (pos.empty()) die("the following required arguments were not provided: <INDEX>");
+            a.index = pos[0];
+            if (pos.size() > 1) a.input = pos[1];
+            if (pos.size() > 2) a.input2 = pos[2], a.has_input2 = true;
+            if (pos.size() > 3) die("unexpected argument '" + pos[3] + "'");
+            return run_filter(a);
+        }
+        if (args[0] == "index" && args.size() >= 2 && args[1] == "build") {
+            std::string input, output = "-";
+            unsigned k = deacon::DEFAULT_KMER_LENGTH, w = deacon::DEFAULT_WINDOW_SIZE;
+            size_t cap = 400;
+            float entropy = 0.0f;
+            bool quiet = false;
+            for (size_t i = 2; i < args.size(); ++i) {
+                const std::string &s = args[i];
+                if (s == "-k") k = (unsigned)std::atoi(need(++i).c_str());
+                else if (s == "-w") w = (unsigned)std::atoi(need(++i).c_str());
+                else if (s == "-o" || s == "--output") output = need(++i);
+                else if (s == "-c" || s == "--capacity") cap = (size_t)std::atoll(need(++i).c_str());
+                else if (s == "-t" || s == "--threads") ++i;
+                else if (s == "-q" || s == "--quiet") quiet = true;
+                else if (s == "-e" || s == "--entropy-threshold") entropy = (float)std::atof(need(++i).c_str());
+                else if (s.size() > 1 && s[0] == '-') die("unexpected argument '" + s + "'");
+                else input = s;
+            }
+            if (input.empty()) die("the following required arguments were not provided: <INPUT>");
+            if (k < 1 || k > 57) die("invalid value for -k: 1..=57");
+            return run_index_build(input, k, w, output, cap, entropy, quiet);
+        }
+        if (args[0] == "index" && args.size() >= 3 && args[1] == "info") return run_index_info(args[2]);
+        usage();
+        return 2;
+    } catch (const deacon::Error &e) {
+        std::fprintf(stderr, "Error: %s\n", e.what());
+        return 1;
+    }
+}

@@ -1,0 +1,272 @@
+"""f2: the `deacon-hip` command-line driver, checked the way the reference checks its own binary
+(tests/filter_tests.rs, tests/index_tests.rs, tests/cli_tests.rs: black-box runs on small FASTA/FASTQ files), plus
+random inputs whose kept records are compared with the oracle's decisions.  Sequence literals come from
+tests/golden/reference_cases.json (data of the reference's tests)."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, mutate, random_reads
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "deacon-server_amd", "bin", "deacon-hip")
+CASES = {c["id"]: c for c in json.load(open(os.path.join(GOLDEN, "reference_cases.json")))["cases"]}
+SEQ1, SEQ2 = CASES["C-7"]["ref"]  # create_test_fasta / create_test_fastq of tests/filter_tests.rs:8-21
+SC2 = CASES["C-1"]["units"][0][0]
+SC2_REV = CASES["C-2"]["units"][0][0]
+SC2B, SC2B_REV = CASES["C-3-fwd"]["units"][0][1], CASES["C-3-rev"]["units"][0][1]
+
+
+def run(*args, stdin=None, check=True):
+    p = subprocess.run([BIN, *map(str, args)], input=stdin, capture_output=True)
+    if check:
+        assert p.returncode == 0, p.stderr.decode()
+    return p
+
+
+def fasta(path, recs):
+    path.write_text("".join(f">{i}\n{s}\n" for i, s in recs))
+
+
+def fastq(path, recs):
+    path.write_text("".join(f"@{i}\n{s}\n+\n{'~' * len(s)}\n" for i, s in recs))
+
+
+def build_index(tmp_path, recs, name="ref", k=None, w=None):
+    fa = tmp_path / f"{name}.fasta"
+    fasta(fa, recs)
+    idx = tmp_path / f"{name}.idx"
+    args = ["index", "build", fa, "-o", idx]
+    if k:
+        args += ["-k", k]
+    if w:
+        args += ["-w", w]
+    run(*args)
+    return idx
+
+
+# ---- no GPU needed ---------------------------------------------------------------------------------------------
+def test_binary_exists_version_and_usage():  # tests/cli_tests.rs
+    assert os.path.exists(BIN), "build with __graft_entry__.build()"
+    assert run("--version").stdout.startswith(b"deacon-hip ")
+    p = run(check=False)
+    assert p.returncode == 2 and b"Usage" in p.stderr
+
+
+def test_filter_fails_loudly_without_gpu(tmp_path, dcn):
+    import ctypes
+    n = ctypes.c_int()
+    if dcn._native.lib().dcn_device_count(ctypes.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    (tmp_path / "x.idx").write_bytes(bytes([2, 31, 15, 0]))
+    fastq(tmp_path / "r.fq", [("a", "ACGT" * 20)])
+    p = run("filter", tmp_path / "x.idx", tmp_path / "r.fq", check=False)
+    assert p.returncode == 1 and b"Error" in p.stderr
+
+
+# ---- the reference's filter tests ------------------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+@gpu
+def test_filter_to_file_and_summary(tmp_path):  # filter_tests.rs:92-128
+    idx = build_index(tmp_path, [("seq1", "A" * 100)])
+    fastq(tmp_path / "reads.fastq", [("seq1", SEQ1), ("seq2", SEQ2)])
+    out, summ = tmp_path / "filtered.fastq", tmp_path / "summary.json"
+    run("filter", idx, tmp_path / "reads.fastq", "--output", out, "--summary", summ)
+    assert out.read_text() == ""
+    s = json.loads(summ.read_text())
+    assert s["seqs_in"] == 2 and s["seqs_out"] == 0 and s["bp_in"] == len(SEQ1) + len(SEQ2)
+    assert s["k"] == 31 and s["w"] == 15 and s["abs_threshold"] == 2 and s["rel_threshold"] == 0.01
+    assert set(s) == {"version", "index", "input", "input2", "output", "output2", "k", "w", "abs_threshold",
+                      "rel_threshold", "prefix_length", "deplete", "rename", "seqs_in", "seqs_out",
+                      "seqs_out_proportion", "seqs_removed", "seqs_removed_proportion", "bp_in", "bp_out",
+                      "bp_out_proportion", "bp_removed", "bp_removed_proportion", "time", "seqs_per_second",
+                      "bp_per_second"}  # FilterSummary, src/filter_common.rs:11-38
+
+
+@gpu
+def test_filter_gzip_output_and_unsupported_codecs(tmp_path):  # filter_tests.rs:131-215
+    idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)])
+    fastq(tmp_path / "reads.fastq", [("seq1", SEQ1), ("seq2", SEQ2)])
+    out = tmp_path / "filtered.fastq.gz"
+    run("filter", idx, tmp_path / "reads.fastq", "-o", out)
+    assert gzip.open(out).read().count(b"@seq") == 2
+    for ext in ("zst", "xz"):  # documented difference: only gzip is available in this build
+        p = run("filter", idx, tmp_path / "reads.fastq", "-o", tmp_path / f"f.fastq.{ext}", check=False)
+        assert p.returncode != 0 and b"not available" in p.stderr
+    gz_in = tmp_path / "reads.fastq.gz"
+    gz_in.write_bytes(gzip.compress((tmp_path / "reads.fastq").read_bytes()))
+    assert run("filter", idx, gz_in).stdout.count(b"@seq") == 2  # compressed input is detected
+
+
+@gpu
+def test_filter_deplete_rename_min_matches_prefix(tmp_path):  # filter_tests.rs:218-341
+    idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)])
+    fastq(tmp_path / "reads.fastq", [("seq1", SEQ1), ("seq2", SEQ2)])
+    fq = tmp_path / "reads.fastq"
+    assert run("filter", idx, fq).stdout.count(b"@seq") == 2
+    assert run("filter", "--deplete", idx, fq).stdout == b""
+    renamed = run("filter", "--rename", idx, fq).stdout.decode().split("\n")
+    assert renamed[0] == "@1" and renamed[4] == "@2" and renamed[1] == SEQ1
+    assert run("filter", "--abs-threshold", "1", idx, fq).stdout.count(b"@seq") == 2
+    assert run("filter", "--prefix-length", "6", idx, fq).stdout == b""  # shorter than k: no minimizers, no crash
+
+
+@gpu
+def test_filter_paired_modes(tmp_path):  # filter_tests.rs:344-583, 726-940
+    idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)])
+    r1, r2 = tmp_path / "r1.fastq", tmp_path / "r2.fastq"
+    fastq(r1, [("read1", SEQ1), ("read2", SEQ2)])
+    fastq(r2, [("read1", SEQ1), ("read2", SEQ2)])
+    out = run("filter", idx, r1, r2).stdout.decode()
+    assert out.count("@read") == 4 and out.split("\n")[0] == "@read1" and out.split("\n")[4] == "@read1"  # interleaved
+    assert run("filter", "-d", idx, r1, r2).stdout == b""
+    ren = run("filter", "-R", idx, r1, r2).stdout.decode().split("\n")
+    assert [ren[i] for i in (0, 4, 8, 12)] == ["@1", "@2", "@3", "@4"]
+    assert run("filter", "-a", "1", idx, r1, r2).stdout.count(b"@read") == 4
+    # interleaved stdin: `- -`
+    inter = "".join(f"@p{i}/{m}\n{s}\n+\n{'~' * len(s)}\n" for i, s in ((1, SEQ1), (2, SEQ2)) for m in (1, 2))
+    got = run("filter", idx, "-", "-", stdin=inter.encode()).stdout.decode()
+    assert got == inter
+    # single stdin
+    single = (tmp_path / "r1.fastq").read_bytes()
+    assert run("filter", idx, "-", stdin=single).stdout == single
+    # --output2: mates to separate files; gzip too; ignored with a warning for single input
+    o1, o2 = tmp_path / "o1.fastq", tmp_path / "o2.fastq"
+    run("filter", idx, r1, r2, "-o", o1, "-O", o2)
+    assert o1.read_text() == r1.read_text() and o2.read_text() == r2.read_text()
+    g1, g2 = tmp_path / "o1.fastq.gz", tmp_path / "o2.fastq.gz"
+    run("filter", idx, r1, r2, "-o", g1, "-O", g2)
+    assert gzip.open(g1).read() == r1.read_bytes() and gzip.open(g2).read() == r2.read_bytes()
+    p = run("filter", idx, r1, "-o", o1, "-O", tmp_path / "ignored.fastq")
+    assert b"--output2 will be ignored" in p.stderr and not (tmp_path / "ignored.fastq").exists()
+
+
+@gpu
+def test_filter_sc2_strands_and_pairs(tmp_path):  # filter_tests.rs:586-723
+    idx = build_index(tmp_path, [("mn908947.3_0:60", SC2)])
+    for name, seq in (("fwd", SC2), ("rev", SC2_REV)):
+        fq = tmp_path / f"{name}.fastq"
+        fastq(fq, [(f"mn908947.3_0:60_{name}", seq)])
+        assert run("filter", "-d", "-a", "1", "-r", "0.01", idx, fq).stdout == b""
+        assert run("filter", "-d", idx, fq).stdout == b""  # default -a 2: the read shares >= 2 minimizers
+        assert run("filter", idx, fq).stdout.count(b"@mn9") == 1
+    for m1, m2 in ((SC2, SC2B), (SC2_REV, SC2B_REV)):
+        fastq(tmp_path / "m1.fastq", [("a/1", m1)])
+        fastq(tmp_path / "m2.fastq", [("a/2", m2)])
+        assert run("filter", "-d", idx, tmp_path / "m1.fastq", tmp_path / "m2.fastq").stdout == b""
+
+
+@gpu
+def test_shared_minimizer_counted_once(tmp_path):  # filter_tests.rs:943-1015
+    c = CASES["C-4"]
+    idx = build_index(tmp_path, [("reference", c["ref"][0])])
+    fasta(tmp_path / "r1.fasta", [("read1/1", c["units"][0][0])])
+    fasta(tmp_path / "r2.fasta", [("read1/2", c["units"][0][1])])
+    summ = tmp_path / "s.json"
+    out = run("filter", "--deplete", idx, tmp_path / "r1.fasta", tmp_path / "r2.fasta", "--summary", summ,
+              "--abs-threshold", "2", "--rel-threshold", "0.01").stdout
+    assert out.count(b">read1") == 2
+    assert json.loads(summ.read_text())["seqs_out"] == 2
+
+
+@gpu
+def test_proportional_thresholds(tmp_path, oracle):  # filter_tests.rs:1018-1130 (the reference only checks success)
+    idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)])
+    fq = tmp_path / "reads.fastq"
+    fastq(fq, [("seq1", SEQ1), ("seq2", SEQ2)])
+    oidx = oracle.Index.build([SEQ1.encode(), SEQ2.encode()])
+    b, o = oracle.concat_reads([SEQ1.encode(), SEQ2.encode()])
+    for rel in ("0.0", "0.01", "0.1", "0.5", "1.0"):
+        keep, hits, total = oracle.filter_batch(oidx, b, o, abs_threshold=1, rel_threshold=float(rel))
+        assert run("filter", "-a", "1", "-r", rel, idx, fq).stdout.count(b"@seq") == int(keep.sum()), rel
+    # periodic reads: 56 minimizers but few distinct ones, so a proportion of 1.0 cannot be met by distinct hits
+    assert total.tolist() == [56, 56] and hits.max() < 56
+
+
+@gpu
+def test_multiline_fasta_and_newline_mapping(tmp_path):  # filter_tests.rs:1133-1251
+    c5 = CASES["C-5"]
+    idx = build_index(tmp_path, [("ref", c5["ref"][0])], k=31, w=1)
+    q = tmp_path / "query.fasta"
+    q.write_text(">query\nACGTTTAAGGCCAACC\nACACACACACACATT\n")
+    out = run("filter", "-a", "1", idx, q).stdout.decode()
+    assert ">query" in out and c5["ref"][0] in out
+    ref = tmp_path / "nl.fa"
+    ref.write_text(">reference\nAAAAA\nAAAAA\nAAAAA\nAAAAA\n")
+    idx2 = tmp_path / "nl.idx"
+    run("index", "build", "-k", "5", "-w", "5", ref, "-o", idx2)
+    q2 = tmp_path / "q2.fa"
+    q2.write_text(">query\nAAAAACAAAAACAAAAACAAAAA\n")
+    assert b">query" not in run("filter", "-a", "1", "-r", "0.0", idx2, q2).stdout
+
+
+@gpu
+def test_large_kmer_filter(tmp_path):  # filter_tests.rs:1254-1296
+    idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)], k=41, w=15)
+    fq = tmp_path / "reads.fastq"
+    fastq(fq, [("seq1", SEQ1), ("seq2", SEQ2)])
+    assert run("filter", idx, fq, "-a", "1", "-r", "0.0").stdout.count(b"@seq") == 2
+
+
+@gpu
+def test_index_build_and_info(tmp_path):  # index_tests.rs:10-166
+    idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)])
+    assert idx.stat().st_size > 4
+    p = run("index", "info", idx)
+    assert b"K-mer length (k): 31" in p.stderr and b"Window size (w): 15" in p.stderr
+    idx2 = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)], name="custom", k=15, w=11)
+    p = run("index", "info", idx2)
+    assert b"K-mer length (k): 15" in p.stderr and b"Window size (w): 11" in p.stderr
+    p = run("index", "build", tmp_path / "ref.fasta", "-k", "31", "-w", "16", check=False)  # k+w-1 even
+    assert p.returncode != 0 and b"must be odd" in p.stderr
+    # stdout output: `deacon index build ref.fa > ref.idx` (how the reference's tests build indexes)
+    raw = run("index", "build", tmp_path / "ref.fasta", "-q").stdout
+    assert raw[:3] == bytes([2, 31, 15]) and len(raw) == idx.stat().st_size
+
+
+# ---- random data against the oracle ------------------------------------------------------------------------------
+@gpu
+@pytest.mark.parametrize("paired", [False, True])
+def test_cli_matches_oracle_on_random_reads(tmp_path, oracle, paired):
+    rng = np.random.default_rng(55)
+    genome = random_reads(rng, 1, 60_000, 60_000)[0]
+    (tmp_path / "g.fa").write_bytes(b">chr1 test genome\n" + b"\n".join(genome[i:i + 70] for i in range(0, len(genome), 70)) + b"\n")
+    idx = tmp_path / "g.idx"
+    run("index", "build", tmp_path / "g.fa", "-o", idx, "-q")
+    oidx = oracle.Index.build([genome])
+    assert oracle.Index.read(idx).keys().tolist().sort() == oidx.keys().tolist().sort()
+    reads = []
+    for i in range(6000):
+        ln = int(rng.integers(25, 300))
+        if rng.random() < 0.5:
+            s = int(rng.integers(0, len(genome) - ln))
+            reads.append(mutate(rng, genome[s:s + ln], 0.02))
+        else:
+            reads.append(random_reads(rng, 1, ln, ln, p_n=0.005)[0])
+    b, o = oracle.concat_reads(reads)
+    summ = tmp_path / "s.json"
+    if paired:
+        fastq(tmp_path / "r1.fq", [(f"r{i}/1 x", reads[2 * i].decode()) for i in range(3000)])
+        fastq(tmp_path / "r2.fq", [(f"r{i}/2 x", reads[2 * i + 1].decode()) for i in range(3000)])
+        out = run("filter", "-d", idx, tmp_path / "r1.fq", tmp_path / "r2.fq", "-s", summ).stdout.decode()
+        keep, _, _ = oracle.filter_batch(oidx, b, o, (np.arange(6000) // 2).astype(np.uint32), deplete=True)
+        want_ids = [f"r{i}/{m} x" for i in range(3000) if keep[i] for m in (1, 2)]
+        lens = np.array([len(r) for r in reads]).reshape(-1, 2).sum(1)
+    else:
+        fastq(tmp_path / "r.fq", [(f"r{i} x", r.decode()) for i, r in enumerate(reads)])
+        out = run("filter", "-d", idx, tmp_path / "r.fq", "-s", summ).stdout.decode()
+        keep, _, _ = oracle.filter_batch(oidx, b, o, deplete=True)
+        want_ids = [f"r{i} x" for i in range(6000) if keep[i]]
+        lens = np.array([len(r) for r in reads])
+    got_ids = [l[1:] for l in out.split("\n")[0::4] if l]
+    assert got_ids == want_ids  # same records, input order
+    s = json.loads(summ.read_text())
+    assert s["seqs_in"] == 6000 and s["seqs_out"] == len(want_ids)
+    assert s["bp_out"] == int(lens[keep].sum()) and s["bp_removed"] == int(lens[~keep].sum())
+    assert s["deplete"] is True and abs(s["seqs_out_proportion"] - len(want_ids) / 6000) < 1e-12

@@ -71,6 +71,8 @@ _SIGNATURES = {
     "dcn_index_build": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint8, C.c_uint8, C.c_float, C.c_uint64, C.c_int,
                                   C.POINTER(_vp)]),
     "dcn_index_keys": (C.c_int, [_vp, _vp, C.c_uint64, _u64p]),
+    "dcn_index_union": (C.c_int, [C.POINTER(_vp), C.c_uint32, C.POINTER(_vp)]),
+    "dcn_index_diff": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "dcn_index_write_file": (C.c_int, [_vp, C.c_char_p]),
     "dcn_index_header": (C.c_int, [_vp, _u8p, _u8p, _u64p]),
     "dcn_index_contains": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),

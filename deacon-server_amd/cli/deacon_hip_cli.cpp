@@ -3,6 +3,8 @@
 //
 //   deacon-hip index build <fastx> [-k 31] [-w 15] [-o out.idx] [-c capacity_millions] [-e entropy] [-q]
 //   deacon-hip index info  <index>
+//   deacon-hip index union <index>... [-o out.idx]
+//   deacon-hip index diff  <first.idx> <second.idx | fastx> [-k K -w W] [-o out.idx]
 //   deacon-hip filter <index> [input|-] [input2|-] [-o out] [-O out2] [-a 2] [-r 0.01] [-p 0] [-d] [-R]
 //                     [-s summary.json] [-t threads] [--compression-level 2] [--debug] [-q]
 //
@@ -11,7 +13,7 @@
 // should_keep_sequence / should_keep_pair) is replaced by batches through dcn_filter_batch: a reader thread parses
 // FASTA/FASTQ (plain or gzip) into batches, the main thread runs them on the GPU, a writer thread formats the kept
 // records (format_record_to_buffer, src/local_filter.rs:60-92).  Output keeps the input order (the reference's
-// order depends on worker scheduling).  `index union/diff` and the server/client commands are not part of this path.
+// order depends on worker scheduling).  The server/client commands are not part of this path.
 // Input/output compression: gzip via zlib; zstd and xz are not available in this build.
 #include <zlib.h>
 
@@ -524,9 +526,86 @@ int run_index_info(const std::string &path) {
     return 0;
 }
 
+void write_index(dcn_index *raw, const std::string &output) {
+    std::string path = output == "-" ? "/dev/stdout" : output;
+    deacon::check(dcn_index_write_file(raw, path.c_str()));
+}
+
+struct RawIndex {  // owns a dcn_index*
+    dcn_index *p = nullptr;
+    ~RawIndex() {
+        if (p) dcn_index_destroy(p);
+    }
+};
+
+// index::union (src/index.rs:563-664)
+int run_index_union(const std::vector<std::string> &inputs, const std::string &output) {
+    auto start = std::chrono::steady_clock::now();
+    std::vector<RawIndex> idx(inputs.size());
+    std::vector<const dcn_index *> ptrs;
+    for (size_t i = 0; i < inputs.size(); ++i) {
+        deacon::check(dcn_index_from_file(inputs[i].c_str(), 0, &idx[i].p));
+        uint64_t n = 0;
+        dcn_index_header(idx[i].p, nullptr, nullptr, &n);
+        std::fprintf(stderr, "Index %zu: %llu minimizers\n", i + 1, (unsigned long long)n);
+        ptrs.push_back(idx[i].p);
+    }
+    RawIndex out;
+    deacon::check(dcn_index_union(ptrs.data(), (uint32_t)ptrs.size(), &out.p));
+    uint64_t n = 0;
+    dcn_index_header(out.p, nullptr, nullptr, &n);
+    std::fprintf(stderr, "Union: %llu minimizers from %zu indexes\n", (unsigned long long)n, inputs.size());
+    write_index(out.p, output);
+    std::fprintf(stderr, "Completed union operation in %s\n",
+                 fmt_duration(std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()).c_str());
+    return 0;
+}
+
+// index::diff (src/index.rs:421-536): second is an index file, or a FASTX file when -k/-w are given or when it does
+// not parse as an index (then the first index's k, w are used)
+int run_index_diff(const std::string &first, const std::string &second, int k_opt, int w_opt, const std::string &output) {
+    auto start = std::chrono::steady_clock::now();
+    RawIndex a, b, out;
+    deacon::check(dcn_index_from_file(first.c_str(), 0, &a.p));
+    uint8_t k = 0, w = 0;
+    uint64_t na = 0;
+    dcn_index_header(a.p, &k, &w, &na);
+    std::fprintf(stderr, "First index: loaded %llu minimizers\n", (unsigned long long)na);
+    bool fastx = k_opt > 0 && w_opt > 0;
+    if (!fastx && dcn_index_from_file(second.c_str(), 0, &b.p) != DCN_OK) {
+        fastx = true;  // not an index file: treat it as FASTX with the first index's parameters
+        k_opt = k;
+        w_opt = w;
+    }
+    if (fastx) {
+        if (k_opt != k || w_opt != w)
+            die("FASTX parameters (k=" + std::to_string(k_opt) + ", w=" + std::to_string(w_opt) + ") must match first index (k=" +
+                std::to_string((int)k) + ", w=" + std::to_string((int)w) + ")");
+        std::fprintf(stderr, "Second index: processing FASTX from %s (k=%d, w=%d)…\n", second == "-" ? "stdin" : "file", k_opt, w_opt);
+        FastxReader rd(second);
+        Batch all;
+        while (rd.next(all)) {
+        }
+        deacon::check(dcn_index_build(all.bases.data(), all.offsets.data(), (uint32_t)all.recs.size(), k, w, 0.0f,
+                                      all.bases.size() / 4 + 1024, 0, &b.p));
+    } else {
+        uint64_t nb = 0;
+        dcn_index_header(b.p, nullptr, nullptr, &nb);
+        std::fprintf(stderr, "Second index: loaded %llu minimizers\n", (unsigned long long)nb);
+    }
+    deacon::check(dcn_index_diff(a.p, b.p, &out.p));
+    uint64_t n = 0;
+    dcn_index_header(out.p, nullptr, nullptr, &n);
+    std::fprintf(stderr, "Removed %llu minimizers, %llu remaining\n", (unsigned long long)(na - n), (unsigned long long)n);
+    write_index(out.p, output);
+    std::fprintf(stderr, "Completed difference operation in %s\n",
+                 fmt_duration(std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()).c_str());
+    return 0;
+}
+
 void usage() {
     std::fprintf(stderr,
-                 "Usage: deacon-hip <COMMAND>\n\nCommands:\n  index   Build and inspect minimizer indexes (build, info)\n"
+                 "Usage: deacon-hip <COMMAND>\n\nCommands:\n  index   Build and compose minimizer indexes (build, info, union, diff)\n"
                  "  filter  Keep or discard DNA fastx records with sufficient minimizer hits to an index\n\n"
                  "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n");
 }
@@ -605,6 +684,23 @@ int main(int argc, char **argv) {
             return run_index_build(input, k, w, output, cap, entropy, quiet);
         }
         if (args[0] == "index" && args.size() >= 3 && args[1] == "info") return run_index_info(args[2]);
+        if (args[0] == "index" && args.size() >= 3 && (args[1] == "union" || args[1] == "diff")) {
+            std::vector<std::string> pos;
+            std::string output = "-";
+            int k_opt = 0, w_opt = 0;
+            for (size_t i = 2; i < args.size(); ++i) {
+                const std::string &s = args[i];
+                if (s == "-o" || s == "--output") output = need(++i);
+                else if (s == "-c" || s == "--capacity") ++i;  // pre-allocation hint only
+                else if (s == "-k" || s == "--kmer-length") k_opt = std::atoi(need(++i).c_str());
+                else if (s == "-w" || s == "--window-size") w_opt = std::atoi(need(++i).c_str());
+                else if (s.size() > 1 && s[0] == '-') die("unexpected argument '" + s + "'");
+                else pos.push_back(s);
+            }
+            if (args[1] == "union") return run_index_union(pos, output);
+            if (pos.size() != 2) die("index diff needs <FIRST> <SECOND>");
+            return run_index_diff(pos[0], pos[1], k_opt, w_opt, output);
+        }
         usage();
         return 2;
     } catch (const deacon::Error &e) {

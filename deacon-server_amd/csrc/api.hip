@@ -126,6 +126,63 @@ extern "C" int dcn_index_build(const uint8_t *bases, const uint64_t *offsets, ui
     return DCN_OK;
 }
 
+static int same_params(const dcn_index *a, const dcn_index *b) {
+    if (a->k != b->k || a->w != b->w)
+        return dcn_fail(DCN_ERR_ARG, "Incompatible headers: k=" + std::to_string((int)b->k) + ", w=" + std::to_string((int)b->w) +
+                                         " vs k=" + std::to_string((int)a->k) + ", w=" + std::to_string((int)a->w));
+    if (a->device != b->device) return dcn_fail(DCN_ERR_ARG, "indexes live on different devices");
+    return DCN_OK;
+}
+
+extern "C" int dcn_index_union(const dcn_index *const *inputs, uint32_t n, dcn_index **out) {
+    if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!inputs || n == 0 || !inputs[0]) return dcn_fail(DCN_ERR_ARG, "at least one input index is required");
+    uint64_t sum = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!inputs[i]) return dcn_fail(DCN_ERR_ARG, "input index is NULL");
+        int rc = same_params(inputs[0], inputs[i]);
+        if (rc != DCN_OK) return rc;
+        sum += inputs[i]->n_keys;  // worst-case capacity, as the reference pre-allocates (src/index.rs:579-594)
+    }
+    dcn_index *idx = new (std::nothrow) dcn_index();
+    if (!idx) return dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
+    idx->device = inputs[0]->device;
+    idx->k = inputs[0]->k;
+    idx->w = inputs[0]->w;
+    int rc = dcn_table_alloc(idx, std::max<uint64_t>(sum, 16));
+    for (uint32_t i = 0; i < n && rc == DCN_OK; ++i) rc = dcn_table_merge(idx, inputs[i], nullptr);
+    if (rc != DCN_OK) {
+        if (idx->d_slots) hipFree(idx->d_slots);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return DCN_OK;
+}
+
+extern "C" int dcn_index_diff(const dcn_index *first, const dcn_index *second, dcn_index **out) {
+    if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!first || !second) return dcn_fail(DCN_ERR_ARG, "index is NULL");
+    int rc = same_params(first, second);
+    if (rc != DCN_OK) return rc;
+    dcn_index *idx = new (std::nothrow) dcn_index();
+    if (!idx) return dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
+    idx->device = first->device;
+    idx->k = first->k;
+    idx->w = first->w;
+    rc = dcn_table_alloc(idx, std::max<uint64_t>(first->n_keys, 16));
+    if (rc == DCN_OK) rc = dcn_table_merge(idx, first, second);
+    if (rc != DCN_OK) {
+        if (idx->d_slots) hipFree(idx->d_slots);
+        delete idx;
+        return rc;
+    }
+    *out = idx;
+    return DCN_OK;
+}
+
 extern "C" int dcn_index_keys(const dcn_index *index, uint64_t *out, uint64_t capacity, uint64_t *n) {
     if (!index || !n) return dcn_fail(DCN_ERR_ARG, "index/n is NULL");
     if (capacity > 0 && !out) return dcn_fail(DCN_ERR_ARG, "out is NULL");

@@ -144,6 +144,7 @@ int dcn_table_insert_dump(dcn_index *idx, const uint64_t *d_hash, const uint8_t 
                           uint64_t n_slots, const uint8_t *d_ascii, float entropy_threshold, hipStream_t stream);
 int dcn_table_count_valid(const uint8_t *d_valid, uint64_t n, uint64_t *count, hipStream_t stream);
 int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity, uint64_t *n_out);
+int dcn_table_merge(dcn_index *dst, const dcn_index *src, const dcn_index *minus);
 
 // exclusive prefix sum of n u32 values into out[0..n] (out[n] = total); tmp holds ceil(n/1024)+1 words
 int dcn_launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *d_tmp,

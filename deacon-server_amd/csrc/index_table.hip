@@ -368,3 +368,70 @@ int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity
     if (e != hipSuccess) return dcn_fail(DCN_ERR_HIP, std::string("export keys: ") + hipGetErrorString(e));
     return DCN_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------
+// set algebra on device tables (f4 of SURVEY.md 8f): index::union (src/index.rs:563-664), index::diff (:421-536)
+// ----------------------------------------------------------------------------------------------------
+namespace {
+// insert every key of `src` that is NOT in `minus` (minus.slots == nullptr: no filter) into dst
+__global__ void table_copy_filtered_kernel(uint64_t *dst, uint32_t dst_shift, uint32_t dst_mask, const uint64_t *src,
+                                           uint64_t src_slots, dcn_table_view minus, unsigned long long *n_new) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long fresh = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < src_slots; i += stride) {
+        uint64_t key = src[i];
+        if (key == 0) continue;
+        if (minus.slots && dcn_table_contains_dev(minus, key)) continue;
+        uint32_t g = dcn_group_of(key, dst_shift, dst_mask);
+        bool done = false;
+        while (!done) {
+            unsigned long long *grp = (unsigned long long *)(dst + (uint64_t)g * DCN_GROUP_SLOTS);
+            for (int s = 0; s < DCN_GROUP_SLOTS && !done; ++s) {
+                unsigned long long cur = __hip_atomic_load(&grp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == key) {
+                    done = true;
+                } else if (cur == 0) {
+                    unsigned long long old = atomicCAS(&grp[s], 0ull, (unsigned long long)key);
+                    if (old == 0) {
+                        fresh++;
+                        done = true;
+                    } else if (old == key) {
+                        done = true;
+                    }
+                }
+            }
+            g = (g + 1) & dst_mask;
+        }
+    }
+    if (fresh) atomicAdd(n_new, fresh);
+}
+} // namespace
+
+// dst (freshly allocated, large enough) += keys of src that are not in `minus` (may be null)
+int dcn_table_merge(dcn_index *dst, const dcn_index *src, const dcn_index *minus) {
+    DCN_HIP(hipSetDevice(dst->device));
+    unsigned long long *d_new = nullptr;
+    DCN_HIP(hipMalloc((void **)&d_new, sizeof(unsigned long long)));
+    DCN_HIP(hipMemset(d_new, 0, sizeof(unsigned long long)));
+    dcn_table_view dv = dst->view();
+    dcn_table_view mv;
+    mv.slots = nullptr;
+    mv.group_shift = 32;
+    mv.group_mask = 0;
+    mv.has_zero = 0;
+    if (minus) mv = minus->view();
+    uint64_t src_slots = src->n_groups * DCN_GROUP_SLOTS;
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((src_slots + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(table_copy_filtered_kernel, dim3(blocks), dim3(256), 0, 0, dst->d_slots, dv.group_shift,
+                       dv.group_mask, src->d_slots, src_slots, mv, d_new);
+    unsigned long long h_new = 0;
+    hipError_t e = hipMemcpy(&h_new, d_new, sizeof(h_new), hipMemcpyDeviceToHost);
+    hipFree(d_new);
+    if (e != hipSuccess) return dcn_fail(DCN_ERR_HIP, std::string("table merge: ") + hipGetErrorString(e));
+    dst->n_keys += h_new;
+    if (src->has_zero && !(minus && minus->has_zero) && !dst->has_zero) {
+        dst->has_zero = true;
+        dst->n_keys += 1;
+    }
+    return DCN_OK;
+}

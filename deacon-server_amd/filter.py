@@ -81,6 +81,20 @@ class Index:
                                         window_size, float(entropy_threshold), int(capacity_keys), device, C.byref(h)))
         return cls(h, device)
 
+    @classmethod
+    def union(cls, indexes):
+        """index::union (index.rs:563-664): set union; all inputs must share k and w."""
+        arr = (C.c_void_p * len(indexes))(*[i._h for i in indexes])
+        h = C.c_void_p()
+        N.check(N.lib().dcn_index_union(arr, len(indexes), C.byref(h)))
+        return cls(h, indexes[0].device)
+
+    def diff(self, other):
+        """index::diff (index.rs:421-536): the minimizers of self that are not in other."""
+        h = C.c_void_p()
+        N.check(N.lib().dcn_index_diff(self._h, other._h, C.byref(h)))
+        return type(self)(h, self.device)
+
     def keys(self):
         """The distinct minimizer hashes (arbitrary order, like iterating the reference's set)."""
         out = np.zeros(max(self.n_keys, 1), np.uint64)

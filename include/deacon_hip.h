@@ -95,6 +95,13 @@ int dcn_index_keys(const dcn_index *index, uint64_t *out, uint64_t capacity, uin
 /* Write the index in the reference's file format: write_minimizers (src/index.rs:130-164). */
 int dcn_index_write_file(const dcn_index *index, const char *path);
 
+/* Set union of n >= 1 indexes on the same device: index::union (src/index.rs:563-664).  All inputs must have the
+ * same k and w (the reference refuses otherwise, :611-626). */
+int dcn_index_union(const dcn_index *const *inputs, uint32_t n, dcn_index **out);
+
+/* Set difference first \ second: index::diff (src/index.rs:421-536); k and w must match (:478-490). */
+int dcn_index_diff(const dcn_index *first, const dcn_index *second, dcn_index **out);
+
 /* Header fields and the number of DISTINCT keys (what `deacon index info` prints, src/index.rs:539-560). */
 int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n_keys);
 

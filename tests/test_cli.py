@@ -230,6 +230,34 @@ def test_index_build_and_info(tmp_path):  # index_tests.rs:10-166
     assert raw[:3] == bytes([2, 31, 15]) and len(raw) == idx.stat().st_size
 
 
+@gpu
+def test_index_union_and_diff(tmp_path, oracle):  # index_tests.rs:86-341
+    rng = np.random.default_rng(3)
+    g1 = random_reads(rng, 1, 20_000, 20_000)[0].decode()
+    g2 = g1[10_000:] + random_reads(rng, 1, 10_000, 10_000)[0].decode()  # overlaps the second half of g1
+    i1 = build_index(tmp_path, [("a", g1)], name="one")
+    i2 = build_index(tmp_path, [("b", g2)], name="two")
+    k1 = set(oracle.Index.read(i1).keys().tolist())
+    k2 = set(oracle.Index.read(i2).keys().tolist())
+    u = tmp_path / "union.idx"
+    run("index", "union", i1, i2, "-o", u)
+    assert set(oracle.Index.read(u).keys().tolist()) == k1 | k2  # index_tests.rs:86-127: size >= each input
+    d = tmp_path / "diff.idx"
+    p = run("index", "diff", i1, i2, "-o", d)
+    assert set(oracle.Index.read(d).keys().tolist()) == k1 - k2 and 0 < len(k1 - k2) < len(k1)
+    assert f"Removed {len(k1 & k2)} minimizers, {len(k1 - k2)} remaining".encode() in p.stderr
+    # three ways to name the second operand agree in count and file size (index_tests.rs:168-341)
+    d2, d3 = tmp_path / "diff_fastx.idx", tmp_path / "diff_auto.idx"
+    run("index", "diff", i1, tmp_path / "two.fasta", "-k", "31", "-w", "15", "-o", d2)
+    run("index", "diff", i1, tmp_path / "two.fasta", "-o", d3)  # FASTX detected, k and w from the first index
+    assert d.stat().st_size == d2.stat().st_size == d3.stat().st_size
+    assert set(oracle.Index.read(d2).keys().tolist()) == set(oracle.Index.read(d3).keys().tolist()) == k1 - k2
+    # mismatching parameters are refused
+    i3 = build_index(tmp_path, [("a", g1)], name="other", k=15, w=11)
+    assert run("index", "union", i1, i3, "-o", tmp_path / "x.idx", check=False).returncode != 0
+    assert run("index", "diff", i1, tmp_path / "two.fasta", "-k", "15", "-w", "11", check=False).returncode != 0
+
+
 # ---- random data against the oracle ------------------------------------------------------------------------------
 @gpu
 @pytest.mark.parametrize("paired", [False, True])

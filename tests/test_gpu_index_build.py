@@ -100,3 +100,24 @@ def test_built_index_filters_like_oracle_index(oracle, dcn):
     got = proc.filter_batch(b, o)
     for g, w_ in zip(got, want):
         assert g.tolist() == w_.tolist()
+
+
+def test_union_and_diff_set_algebra(oracle, dcn):
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 2**63, 200_000, dtype=np.uint64)
+    b = np.concatenate([a[50_000:120_000], rng.integers(0, 2**63, 100_000, dtype=np.uint64), np.zeros(1, np.uint64)])
+    c = np.concatenate([a[:10], np.zeros(1, np.uint64)])
+    ia, ib, ic = (dcn.Index.from_keys(x, 31, 15) for x in (a, b, c))
+    sa, sb, sc = set(a.tolist()), set(b.tolist()), set(c.tolist())
+    u = dcn.Index.union([ia, ib, ic])
+    assert u.n_keys == len(sa | sb | sc) and set(u.keys().tolist()) == sa | sb | sc
+    assert set(ia.diff(ib).keys().tolist()) == sa - sb
+    assert set(ib.diff(ia).keys().tolist()) == sb - sa          # keeps key 0 (only in b)
+    assert set(ib.diff(ic).keys().tolist()) == sb - sc          # drops key 0 (in both)
+    assert ia.diff(ia).n_keys == 0
+    assert dcn.Index.union([ia]).n_keys == len(sa)
+    other = dcn.Index.from_keys(a[:10], 15, 11)
+    with pytest.raises(dcn.DeaconHipError):
+        dcn.Index.union([ia, other])
+    with pytest.raises(dcn.DeaconHipError):
+        ia.diff(other)

@@ -84,7 +84,7 @@ struct IntTag {
     static constexpr int value = N;
 };
 #ifndef DCN_U_FINAL
-#define DCN_U_FINAL 2 // items per lane per phase-B group in the final flush (1..4 measure the same)
+#define DCN_U_FINAL 1 // items per lane per phase-B group in the final flush (measured 1..8: 1 is best)
 #endif
 
 // W > 0: window size known at compile time, ring in registers.  W == 0: runtime w, ring in dynamic LDS.
@@ -175,6 +175,9 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
     // flush (scan registers dead) uses DCN_U_FINAL, a mid-scan flush 1.
     auto flush = [&](auto u_tag, bool final_flush) {
         constexpr int U = decltype(u_tag)::value;
+#ifdef DCN_PHASEB_PRIO
+        __builtin_amdgcn_s_setprio(DCN_PHASEB_PRIO); // latency-bound phase: let its few instructions issue first
+#endif
         const uint32_t skip0 = (first_pending && cnt > 0) ? 1u : 0u;
         const uint32_t cnt_eff = cnt - skip0;
         uint32_t incl = wave_inclusive_scan_u32(cnt_eff, lane);
@@ -389,6 +392,9 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
         if (skip0) first_pending = false;
         cnt = 0;
         __syncthreads();
+#ifdef DCN_PHASEB_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     };
 
     // ---- phase A: rolling scan in blocks of STEP bases ---------------------------------------------------------

@@ -2,7 +2,7 @@
 // which the kernels of the batch pipeline are enqueued.
 //
 // One batch on the context's compute stream:
-//   memset(per-unit scratch) -> pack (K1) -> plan_reads -> prefix sum -> plan_tiles -> scan (K2-K5, fused)
+//   memset(per-unit scratch) -> pack (K1) -> plan (one launch) -> scan (K2-K5, fused)
 //   -> distinct pass for multi-wave units -> finish (decision + six counters, K6)
 // Host batches are staged through two pinned buffers and copied with hipMemcpyAsync on a side stream while
 // the host fills the other buffer; the compute stream waits on the copy's event.
@@ -251,7 +251,7 @@ struct dcn_ctx {
     uint32_t *d_packed = nullptr, *d_invmask = nullptr; // allocations (views skip DCN_FRONT_PAD words)
     // plan
     uint32_t *d_read_windows = nullptr, *d_read_tiles = nullptr, *d_read_tile_first = nullptr;
-    uint32_t *d_unit_first_read = nullptr, *d_unit_tile_first = nullptr;
+    uint32_t *d_unit_first_read = nullptr, *d_unit_tile_first = nullptr, *d_unit_tile_count = nullptr;
     dcn_tile *d_tiles = nullptr;
     uint32_t *d_scan_tmp = nullptr;
     // per-unit results / scratch
@@ -329,7 +329,7 @@ void free_ctx(dcn_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask, c->d_read_windows,
-                   c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_tiles,
+                   c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
                    c->d_scan_tmp, c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
                    c->d_set_off, c->d_rec_unit, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
@@ -423,11 +423,11 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     pa.read_tile_first = c->d_read_tile_first;
     pa.unit_first_read = c->d_unit_first_read;
     pa.unit_tile_first = c->d_unit_tile_first;
+    pa.unit_tile_count = c->d_unit_tile_count;
+    pa.tile_cursor = &c->d_status->n_tiles;
     pa.tiles = c->d_tiles;
     pa.status = c->d_status;
-    DCN_TRY(dcn_launch_plan_reads(pa, st));
-    DCN_TRY(dcn_launch_exclusive_scan(c->d_read_tiles, c->d_read_tile_first, n_reads, c->d_scan_tmp, st));
-    DCN_TRY(dcn_launch_plan_tiles(pa, st));
+    DCN_TRY(dcn_launch_plan(pa, st));
     DCN_PROF_MARK(DCN_STAGE_PLAN);
 
     uint32_t *g_total = c->d_unit_scratch, *g_hitcnt = g_total + c->max_reads, *g_distinct = g_hitcnt + c->max_reads,
@@ -439,6 +439,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     sa.tiles = c->d_tiles;
     sa.n_tiles = &c->d_status->n_tiles;
     sa.unit_tile_first = c->d_unit_tile_first;
+    sa.unit_tile_count = c->d_unit_tile_count;
     sa.table = idx->view();
     sa.k = idx->k;
     sa.w = idx->w;
@@ -605,6 +606,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_read_tile_first, MR + 1, "read_tile_first");
     A(d_unit_first_read, MR + 1, "unit_first_read");
     A(d_unit_tile_first, MR + 1, "unit_tile_first");
+    A(d_unit_tile_count, MR + 1, "unit_tile_count");
     A(d_tiles, mt, "tiles");
     A(d_scan_tmp, dcn_scan_tmp_words(max_batch_reads) + 8, "scan_tmp");
     A(d_keep, MR, "keep");
@@ -785,11 +787,11 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     pa.read_tile_first = c->d_read_tile_first;
     pa.unit_first_read = c->d_unit_first_read;
     pa.unit_tile_first = c->d_unit_tile_first;
+    pa.unit_tile_count = c->d_unit_tile_count;
+    pa.tile_cursor = &c->d_status->n_tiles;
     pa.tiles = c->d_tiles;
     pa.status = c->d_status;
-    DCN_TRY(dcn_launch_plan_reads(pa, st));
-    DCN_TRY(dcn_launch_exclusive_scan(c->d_read_tiles, c->d_read_tile_first, n_reads, c->d_scan_tmp, st));
-    DCN_TRY(dcn_launch_plan_tiles(pa, st));
+    DCN_TRY(dcn_launch_plan(pa, st));
     dcn_scan_args sa;
     memset(&sa, 0, sizeof(sa));
     sa.packed = packed;
@@ -809,9 +811,11 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     DCN_HIP(hipStreamSynchronize(st));
     // gather on the host: tiles are in read order, a tile's entries sit at [first own window's absolute
     // base index ...) in emit order; entries failing the ACGT test are dropped (src/filter_common.rs:275-286)
-    std::vector<uint32_t> rtf(n_reads + 1);
-    DCN_HIP(hipMemcpy(rtf.data(), c->d_read_tile_first, (uint64_t)(n_reads + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    uint32_t nt = rtf[n_reads];
+    std::vector<uint32_t> rtf(n_reads), rtn(n_reads);
+    DCN_HIP(hipMemcpy(rtf.data(), c->d_read_tile_first, (uint64_t)n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    DCN_HIP(hipMemcpy(rtn.data(), c->d_read_tiles, (uint64_t)n_reads * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t nt = 0;
+    DCN_HIP(hipMemcpy(&nt, &c->d_status->n_tiles, sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<dcn_tile> tiles(nt);
     std::vector<uint32_t> tcount(nt);
     std::vector<uint64_t> h(n_bases + 2);
@@ -826,7 +830,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     }
     uint64_t n_out = 0;
     for (uint32_t r = 0; r < n_reads; ++r) {
-        for (uint32_t t = rtf[r]; t < rtf[r + 1]; ++t) {
+        for (uint32_t t = rtf[r]; t < rtf[r] + rtn[r]; ++t) {
             uint64_t base = tiles[t].scan_start + (tiles[t].flags & 1u);
             for (uint32_t e = 0; e < tcount[t]; ++e) {
                 if (!v[base + e]) continue;
@@ -996,11 +1000,13 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             pa.read_tile_first = c->d_read_tile_first;
             pa.unit_first_read = c->d_unit_first_read;
             pa.unit_tile_first = c->d_unit_tile_first;
+            pa.unit_tile_count = c->d_unit_tile_count;
+            pa.tile_cursor = &c->d_status->n_tiles;
+    pa.unit_tile_count = c->d_unit_tile_count;
+    pa.tile_cursor = &c->d_status->n_tiles;
             pa.tiles = c->d_tiles;
             pa.status = c->d_status;
-            DCN_TRY(dcn_launch_plan_reads(pa, st));
-            DCN_TRY(dcn_launch_exclusive_scan(c->d_read_tiles, c->d_read_tile_first, np, c->d_scan_tmp, st));
-            DCN_TRY(dcn_launch_plan_tiles(pa, st));
+            DCN_TRY(dcn_launch_plan(pa, st));
             dcn_scan_args sa;
             memset(&sa, 0, sizeof(sa));
             sa.packed = packed;

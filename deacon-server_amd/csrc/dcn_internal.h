@@ -103,7 +103,8 @@ struct dcn_scan_args {
     const uint32_t *invmask; // 1 bit per base, same padding (in 32-bit words)
     const dcn_tile *tiles;
     const uint32_t *n_tiles; // device-side tile count
-    const uint32_t *unit_tile_first; // n_units+1: first tile index of each unit
+    const uint32_t *unit_tile_first; // n_units: first tile index of each unit
+    const uint32_t *unit_tile_count; // n_units: number of tiles, 0xFFFFFFFF when they are not contiguous
     dcn_table_view table;
     uint32_t k, w;
     // thresholds

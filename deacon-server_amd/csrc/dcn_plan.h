@@ -12,11 +12,13 @@ struct dcn_plan_args {
     uint64_t prefix_length;
     uint32_t tile_windows;
     uint32_t *read_windows;     // n_reads
-    uint32_t *read_tiles;       // n_reads
-    uint32_t *read_tile_first;  // n_reads + 1 (exclusive scan of read_tiles)
+    uint32_t *read_tiles;       // n_reads: tiles of each read
+    uint32_t *read_tile_first;  // n_reads: first tile of each read (tile ranges of different reads never overlap)
     uint32_t *unit_first_read;  // n_units + 1 (only written when unit_id != null)
-    uint32_t *unit_tile_first;  // n_units + 1
+    uint32_t *unit_tile_first;  // n_units: first tile of the unit
+    uint32_t *unit_tile_count;  // n_units: its tile count; 0xFFFFFFFF = tiles not contiguous (never resolved in-wave)
     dcn_tile *tiles;
+    uint32_t *tile_cursor;      // global tile counter (= &status->n_tiles, zeroed per batch)
     dcn_status *status;
 };
 
@@ -62,8 +64,7 @@ struct dcn_probe_hashes_args {
     dcn_status *status;
 };
 
-int dcn_launch_plan_reads(const dcn_plan_args &a, hipStream_t stream);
-int dcn_launch_plan_tiles(const dcn_plan_args &a, hipStream_t stream);
+int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream);
 int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *d_scan_tmp, hipStream_t stream);
 int dcn_launch_finish(const dcn_finish_args &a, hipStream_t stream);
 int dcn_launch_probe_hashes(const dcn_probe_hashes_args &a, hipStream_t stream);

@@ -15,20 +15,6 @@ __device__ inline uint32_t effective_windows(const uint8_t *ascii, uint64_t off,
     return n >= l ? (uint32_t)(n - l + 1) : 0;
 }
 
-__global__ __launch_bounds__(256) void plan_reads_kernel(dcn_plan_args a) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.n_reads) return;
-    uint64_t off = a.offsets[r], len = a.offsets[r + 1] - off;
-    uint32_t nwin = effective_windows(a.ascii, off, len, a.prefix_length, a.k, a.k + a.w - 1);
-    a.read_windows[r] = nwin;
-    a.read_tiles[r] = (nwin + a.tile_windows - 1) / a.tile_windows;
-    if (a.unit_id) {
-        uint32_t u = a.unit_id[r];
-        if (r == 0 || a.unit_id[r - 1] != u) a.unit_first_read[u] = r;
-        if (r == a.n_reads - 1) a.unit_first_read[a.n_units] = a.n_reads;
-    }
-}
-
 __device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32_t j, uint64_t off, uint32_t nwin,
                                   uint32_t unit) {
     uint32_t wstart = j * a.tile_windows;
@@ -42,38 +28,109 @@ __device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32
     a.tiles[first + j] = t;
 }
 
-__global__ __launch_bounds__(256) void plan_tiles_kernel(dcn_plan_args a) {
-    // a thread writes the first few tiles of its read; reads with more tiles (long reads, chromosomes during an
-    // index build) are finished by the whole workgroup in a block-stride loop
-    constexpr uint32_t OWN = 4;
-    __shared__ uint32_t long_reads[256];
+// One launch plans the whole batch.  A workgroup takes PLAN_READS consecutive reads (8 per thread): effective lengths
+// -> tile counts, a block-level exclusive sum, ONE atomicAdd on the global tile cursor for the block's range (a single
+// word takes only ~88 atomics/us, hence the large block), then the tile descriptors.  Tiles of one read are
+// consecutive, and so are the tiles of a unit whose reads sit in one workgroup (pairs always do: the block size is
+// even); the order of the blocks' ranges is arbitrary, which nothing depends on: units carry (first tile, tile
+// count).  A unit cut by a workgroup boundary is marked non-contiguous.
+// PLAN_CH = reads per thread: 8 for batches of many short reads (few cursor atomics), 1 when reads are few / long
+// (more workgroups, and the per-workgroup loop over long reads stays short).
+template <uint32_t PLAN_CH>
+__global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
+    constexpr uint32_t PLAN_READS = 256 * PLAN_CH;
+    constexpr uint32_t OWN = 4; // tiles a thread writes itself; longer reads are finished by the whole workgroup
+    __shared__ uint32_t s_tiles[PLAN_READS];
+    __shared__ uint32_t s_first[PLAN_READS];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t long_reads[PLAN_READS];
     __shared__ uint32_t n_long;
-    if (threadIdx.x == 0) n_long = 0;
-    __syncthreads();
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < a.n_reads) {
-        uint32_t first = a.read_tile_first[r], nt = a.read_tile_first[r + 1] - first;
-        uint32_t u = a.unit_id ? a.unit_id[r] : r;
-        bool unit_head = a.unit_id ? (r == 0 || a.unit_id[r - 1] != u) : true;
-        if (unit_head) a.unit_tile_first[u] = first;
-        if (r == a.n_reads - 1) {
-            uint32_t total = a.read_tile_first[a.n_reads];
-            a.unit_tile_first[a.n_units] = total;
-            a.status->n_tiles = total;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t block_first = blockIdx.x * PLAN_READS;
+    const uint32_t block_end = min(a.n_reads, block_first + PLAN_READS);
+    if (tid == 0) n_long = 0;
+    uint32_t nwin[PLAN_CH], nt[PLAN_CH], loc[PLAN_CH];
+    uint32_t carry = 0; // tiles of the chunks before this one
+#pragma unroll
+    for (uint32_t c = 0; c < PLAN_CH; ++c) {
+        const uint32_t r = block_first + c * 256 + tid;
+        nwin[c] = 0;
+        nt[c] = 0;
+        if (r < a.n_reads) {
+            uint64_t off = a.offsets[r];
+            nwin[c] = effective_windows(a.ascii, off, a.offsets[r + 1] - off, a.prefix_length, a.k, a.k + a.w - 1);
+            nt[c] = (nwin[c] + a.tile_windows - 1) / a.tile_windows;
         }
-        uint32_t nwin = a.read_windows[r];
-        uint64_t off = a.offsets[r];
-        for (uint32_t j = 0; j < min(nt, OWN); ++j) write_tile(a, first, j, off, nwin, u);
-        if (nt > OWN) long_reads[atomicAdd(&n_long, 1u)] = r;
+        uint32_t inc = nt[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(inc, d, 64);
+            if ((int)(tid & 63) >= d) inc += o;
+        }
+        __syncthreads(); // s_wave free again
+        if ((tid & 63) == 63) s_wave[tid >> 6] = inc;
+        __syncthreads();
+        uint32_t wave_base = 0, chunk_total = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            if (i < (tid >> 6)) wave_base += s_wave[i];
+            chunk_total += s_wave[i];
+        }
+        loc[c] = carry + wave_base + inc - nt[c];
+        carry += chunk_total;
+        s_tiles[c * 256 + tid] = nt[c];
+    }
+    if (tid == 0) s_base = carry ? atomicAdd(a.tile_cursor, carry) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < PLAN_CH; ++c) s_first[c * 256 + tid] = s_base + loc[c];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < PLAN_CH; ++c) {
+        const uint32_t r = block_first + c * 256 + tid;
+        if (r >= a.n_reads) continue;
+        const uint32_t first = s_base + loc[c];
+        a.read_windows[r] = nwin[c];
+        a.read_tiles[r] = nt[c];
+        a.read_tile_first[r] = first;
+        uint32_t u = r;
+        bool unit_head = true;
+        if (a.unit_id) {
+            u = a.unit_id[r];
+            unit_head = r == 0 || a.unit_id[r - 1] != u;
+            if (unit_head) a.unit_first_read[u] = r;
+            if (r == a.n_reads - 1) a.unit_first_read[a.n_units] = a.n_reads;
+        }
+        if (unit_head) {
+            uint32_t count = nt[c];
+            if (a.unit_id) {
+                // the unit's other reads follow; they are contiguous in tile space only inside this workgroup
+                uint32_t q = r + 1;
+                while (q < a.n_reads && a.unit_id[q] == u) {
+                    if (q >= block_end) {
+                        count = 0xFFFFFFFFu;
+                        break;
+                    }
+                    count += s_tiles[q - block_first];
+                    ++q;
+                }
+            }
+            a.unit_tile_first[u] = first;
+            a.unit_tile_count[u] = count;
+        }
+        const uint64_t off = a.offsets[r];
+        for (uint32_t j = 0; j < min(nt[c], OWN); ++j) write_tile(a, first, j, off, nwin[c], u);
+        if (nt[c] > OWN) long_reads[atomicAdd(&n_long, 1u)] = c * 256 + tid;
     }
     __syncthreads();
     for (uint32_t q = 0; q < n_long; ++q) {
-        uint32_t lr = long_reads[q];
-        uint32_t first = a.read_tile_first[lr], nt = a.read_tile_first[lr + 1] - first;
-        uint32_t u = a.unit_id ? a.unit_id[lr] : lr;
-        uint32_t nwin = a.read_windows[lr];
-        uint64_t off = a.offsets[lr];
-        for (uint32_t j = OWN + threadIdx.x; j < nt; j += blockDim.x) write_tile(a, first, j, off, nwin, u);
+        const uint32_t li = long_reads[q], lr = block_first + li;
+        const uint32_t lnt = s_tiles[li], lfirst = s_first[li];
+        const uint32_t lu = a.unit_id ? a.unit_id[lr] : lr;
+        const uint64_t loff = a.offsets[lr];
+        const uint32_t lnwin = effective_windows(a.ascii, loff, a.offsets[lr + 1] - loff, a.prefix_length, a.k, a.k + a.w - 1);
+        for (uint32_t j = OWN + tid; j < lnt; j += blockDim.x) write_tile(a, lfirst, j, loff, lnwin, lu);
     }
 }
 
@@ -247,14 +304,11 @@ inline uint32_t blocks_for(uint64_t n, uint32_t cap = 256 * 16) {
 
 } // namespace
 
-int dcn_launch_plan_reads(const dcn_plan_args &a, hipStream_t stream) {
-    hipLaunchKernelGGL(plan_reads_kernel, dim3((a.n_reads + 255) / 256), dim3(256), 0, stream, a);
-    DCN_HIP(hipGetLastError());
-    return DCN_OK;
-}
-
-int dcn_launch_plan_tiles(const dcn_plan_args &a, hipStream_t stream) {
-    hipLaunchKernelGGL(plan_tiles_kernel, dim3((a.n_reads + 255) / 256), dim3(256), 0, stream, a);
+int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream) {
+    if (a.n_reads >= (1u << 19))
+        hipLaunchKernelGGL(plan_kernel<8>, dim3((a.n_reads + 2047) / 2048), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(plan_kernel<1>, dim3((a.n_reads + 255) / 256), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }

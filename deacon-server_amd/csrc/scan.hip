@@ -121,8 +121,8 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
         sh.unit_of[uslot] = t.unit;
         bool loc = false;
         if (!DUMP) {
-            uint32_t first = a.unit_tile_first[t.unit], last = a.unit_tile_first[t.unit + 1];
-            loc = first >= wave_first && last <= wave_first + DCN_WAVE;
+            uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
+            loc = count != 0xFFFFFFFFu && first >= wave_first && first + count <= wave_first + DCN_WAVE;
         }
         sh.local[uslot] = loc ? 1 : 0;
     }

@@ -15,6 +15,10 @@
 // records (format_record_to_buffer, src/local_filter.rs:60-92).  Output keeps the input order (the reference's
 // order depends on worker scheduling).  The server/client commands are not part of this path.
 // Input/output compression: gzip via zlib; zstd and xz are not available in this build.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -24,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -91,7 +97,7 @@ class Output {
             if (!f_) die("Failed to create output file: " + path);
             own_ = true;
         }
-        if (f_) std::setvbuf(f_, nullptr, _IOFBF, 8 << 20);  // OUTPUT_BUFFER_SIZE
+        if (f_) std::setvbuf(f_, nullptr, _IONBF, 0);  // batches arrive as multi-megabyte buffers: no second copy
     }
     ~Output() { close(); }
     void write(const std::vector<char> &buf) {
@@ -119,16 +125,21 @@ class Output {
 };
 
 // ---- FASTA / FASTQ records -------------------------------------------------------------------------------------
+constexpr uint64_t NO_QUAL = ~0ull;
 struct Rec {
-    uint32_t id_off, id_len;  // header line without the leading '>' / '@', in Batch::text
-    uint64_t seq_off;         // newline-free sequence in Batch::bases
+    uint64_t id_off;   // header line without the leading '>' / '@', in Batch::chars()
+    uint32_t id_len;
     uint32_t seq_len;
-    uint32_t qual_off;        // in Batch::text; UINT32_MAX for FASTA
+    uint64_t seq_off;  // newline-free sequence in Batch::bases
+    uint64_t qual_off; // in Batch::chars(); NO_QUAL for FASTA
 };
 
 struct Batch {
     uint64_t seq_no = 0;
-    std::vector<char> text;      // ids and qualities
+    std::vector<char> text;      // ids and qualities (streaming reader) ...
+    const char *ext = nullptr;   // ... or the memory-mapped input file they live in (parallel reader)
+    const char *chars() const { return ext ? ext : text.data(); }
+    std::vector<char> out1, out2;  // formatted kept records (filled by the format stage)
     std::vector<uint8_t> bases;  // concatenated sequences (what dcn_filter_batch takes)
     std::vector<uint64_t> offsets{0};
     std::vector<uint32_t> unit_id;
@@ -159,7 +170,7 @@ class FastxReader {
         char marker = line[0];
         if (marker != '>' && marker != '@') die("Invalid FASTX record start: expected '>' or '@'");
         Rec r;
-        r.id_off = (uint32_t)b.text.size();
+        r.id_off = b.text.size();
         r.id_len = (uint32_t)line.size() - 1;
         b.text.insert(b.text.end(), line.begin() + 1, line.end());
         r.seq_off = b.bases.size();
@@ -169,13 +180,13 @@ class FastxReader {
                 if (!getline(line)) break;
                 b.bases.insert(b.bases.end(), line.begin(), line.end());
             }
-            r.qual_off = UINT32_MAX;
+            r.qual_off = NO_QUAL;
         } else {
             if (!getline(line)) die("Truncated FASTQ record");
             b.bases.insert(b.bases.end(), line.begin(), line.end());
             if (!getline(line) || line.empty() || line[0] != '+') die("Invalid FASTQ record: missing '+' line");
             if (!getline(line)) die("Truncated FASTQ record");
-            r.qual_off = (uint32_t)b.text.size();
+            r.qual_off = b.text.size();
             b.text.insert(b.text.end(), line.begin(), line.end());
             if (line.size() != b.bases.size() - r.seq_off) die("FASTQ sequence and quality lengths differ");
         }
@@ -259,6 +270,218 @@ class Queue {  // bounded hand-off between the pipeline threads
     bool done_ = false;
 };
 
+
+// A pool of workers applying fn to batches; results come out in push order (the GPU stage and the writer need order).
+class OrderedStage {
+  public:
+    OrderedStage(size_t threads, size_t max_inflight, std::function<void(Batch &)> fn)
+        : fn_(std::move(fn)), max_inflight_(max_inflight) {
+        for (size_t i = 0; i < threads; ++i) workers_.emplace_back([this] { work(); });
+    }
+    ~OrderedStage() {
+        finish();
+        for (auto &t : workers_) t.join();
+    }
+    void push(std::unique_ptr<Batch> b) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return inflight_ < max_inflight_; });
+        todo_.emplace_back(next_push_++, std::move(b));
+        ++inflight_;
+        cv_.notify_all();
+    }
+    bool pop(std::unique_ptr<Batch> &out) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return done_.count(next_pop_) || (finished_ && next_pop_ == next_push_); });
+        auto it = done_.find(next_pop_);
+        if (it == done_.end()) return false;
+        out = std::move(it->second);
+        done_.erase(it);
+        ++next_pop_;
+        --inflight_;
+        cv_.notify_all();
+        return true;
+    }
+    void finish() {
+        std::lock_guard<std::mutex> l(m_);
+        finished_ = true;
+        cv_.notify_all();
+    }
+
+  private:
+    void work() {
+        for (;;) {
+            std::pair<uint64_t, std::unique_ptr<Batch>> job;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [&] { return !todo_.empty() || finished_; });
+                if (todo_.empty()) return;
+                job = std::move(todo_.front());
+                todo_.pop_front();
+            }
+            fn_(*job.second);
+            std::lock_guard<std::mutex> l(m_);
+            done_.emplace(job.first, std::move(job.second));
+            cv_.notify_all();
+        }
+    }
+    std::function<void(Batch &)> fn_;
+    size_t max_inflight_, inflight_ = 0;
+    uint64_t next_push_ = 0, next_pop_ = 0;
+    bool finished_ = false;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::pair<uint64_t, std::unique_ptr<Batch>>> todo_;
+    std::map<uint64_t, std::unique_ptr<Batch>> done_;
+    std::vector<std::thread> workers_;
+};
+
+// ---- parallel ingest of a plain (uncompressed) regular file: mmap + record-aligned chunks -----------------------
+struct MappedFile {
+    const char *data = nullptr;
+    size_t size = 0;
+    bool open(const std::string &path) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) {
+            ::close(fd);
+            return false;
+        }
+        void *p = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        data = (const char *)p;
+        size = (size_t)st.st_size;
+        if ((unsigned char)data[0] == 0x1f && (unsigned char)data[1] == 0x8b) {  // gzip: use the streaming reader
+            munmap(p, size);
+            data = nullptr;
+            return false;
+        }
+        madvise(p, size, MADV_SEQUENTIAL);
+        return true;
+    }
+    ~MappedFile() {
+        if (data) munmap((void *)data, size);
+    }
+};
+
+inline size_t line_end(const char *d, size_t size, size_t p) {  // index of the '\n' ending the line at p (or size)
+    const void *nl = p < size ? std::memchr(d + p, '\n', size - p) : nullptr;
+    return nl ? (size_t)((const char *)nl - d) : size;
+}
+
+// first record start at or after `from` (a line start): FASTA: a line beginning with '>'; FASTQ: a line beginning
+// with '@' whose third line begins with '+' and whose second and fourth lines have equal length
+size_t next_record_start(const char *d, size_t size, size_t from, bool fastq) {
+    size_t p = from;
+    if (p > 0 && p < size && d[p - 1] != '\n') p = line_end(d, size, p) + 1;  // align to a line start
+    while (p < size) {
+        if (!fastq) {
+            if (d[p] == '>') return p;
+        } else if (d[p] == '@') {
+            size_t e0 = line_end(d, size, p), e1 = line_end(d, size, e0 + 1), e2 = line_end(d, size, e1 + 1);
+            size_t e3 = line_end(d, size, e2 + 1);
+            if (e1 + 1 < size && d[e1 + 1] == '+' && e2 < size) {
+                size_t l1 = e1 - (e0 + 1), l3 = e3 - (e2 + 1);
+                if (l1 && d[e1 - 1] == '\r') --l1;
+                if (l3 && e3 > e2 + 1 && d[e3 - 1] == '\r') --l3;
+                if (l1 == l3) return p;
+            }
+        }
+        p = line_end(d, size, p) + 1;
+    }
+    return size;
+}
+
+// parse the records in [a, b) of the mapped file into batch (ids / qualities stay in the mapping)
+void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
+    out.ext = d;
+    size_t p = a;
+    auto trim = [&](size_t s0, size_t e) { return (e > s0 && d[e - 1] == '\r') ? e - 1 : e; };
+    while (p < b) {
+        size_t e0 = line_end(d, b, p);
+        if (e0 == p) {  // blank line
+            p = e0 + 1;
+            continue;
+        }
+        if (d[p] != (fastq ? '@' : '>')) die("Invalid FASTX record start: expected '>' or '@'");
+        Rec r;
+        r.id_off = p + 1;
+        r.id_len = (uint32_t)(trim(p + 1, e0) - (p + 1));
+        r.seq_off = out.bases.size();
+        if (fastq) {
+            size_t s1 = e0 + 1, e1 = line_end(d, b, s1), s2 = e1 + 1, e2 = line_end(d, b, s2), s3 = e2 + 1, e3 = line_end(d, b, s3);
+            if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
+            size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
+            out.bases.insert(out.bases.end(), d + s1, d + t1);
+            if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
+            r.qual_off = s3;
+            p = e3 + 1;
+        } else {
+            size_t q = e0 + 1;
+            while (q < b && d[q] != '>') {
+                size_t e = line_end(d, b, q);
+                out.bases.insert(out.bases.end(), d + q, d + trim(q, e));
+                q = e + 1;
+            }
+            r.qual_off = NO_QUAL;
+            p = q;
+        }
+        r.seq_len = (uint32_t)(out.bases.size() - r.seq_off);
+        out.recs.push_back(r);
+        out.offsets.push_back(out.bases.size());
+    }
+}
+
+struct BatchStats {
+    uint64_t total_seqs = 0, filtered_seqs = 0, total_bp = 0, output_bp = 0, filtered_bp = 0, kept_records = 0;
+};
+
+// format_record_to_buffer (src/local_filter.rs:60-92) for every kept record of the batch; mate 2 goes to out2 when
+// split_mates; rename_base = records written before this batch (global numbering, see the file header)
+BatchStats format_batch(Batch &b, bool rename, bool split_mates, uint64_t rename_base) {
+    BatchStats st;
+    b.out1.clear();
+    b.out2.clear();
+    const char *chars = b.chars();
+    size_t per_unit = b.paired ? 2 : 1;
+    uint64_t counter = rename_base;
+    for (size_t i = 0; i < b.recs.size(); ++i) {
+        const Rec &r = b.recs[i];
+        size_t u = i / per_unit;
+        st.total_seqs++;
+        st.total_bp += r.seq_len;
+        if (!b.keep[u]) {
+            st.filtered_seqs++;
+            st.filtered_bp += r.seq_len;
+            continue;
+        }
+        st.output_bp += r.seq_len;
+        st.kept_records++;
+        counter++;
+        std::vector<char> &dst = (split_mates && (i & 1)) ? b.out2 : b.out1;
+        bool fasta = r.qual_off == NO_QUAL;
+        dst.push_back(fasta ? '>' : '@');
+        if (rename) {
+            char num[24];
+            int n = std::snprintf(num, sizeof num, "%llu", (unsigned long long)counter);
+            dst.insert(dst.end(), num, num + n);
+        } else {
+            dst.insert(dst.end(), chars + r.id_off, chars + r.id_off + r.id_len);
+        }
+        dst.push_back('\n');
+        dst.insert(dst.end(), b.bases.begin() + r.seq_off, b.bases.begin() + r.seq_off + r.seq_len);
+        if (fasta) {
+            dst.push_back('\n');
+        } else {
+            dst.insert(dst.end(), {'\n', '+', '\n'});
+            dst.insert(dst.end(), chars + r.qual_off, chars + r.qual_off + r.seq_len);
+            dst.push_back('\n');
+        }
+    }
+    return st;
+}
+
 std::string fmt_duration(double s) {  // like Rust's {:.2?} for Duration
     char b[64];
     if (s >= 1.0) std::snprintf(b, sizeof b, "%.2fs", s);
@@ -338,89 +561,103 @@ int run_filter(const FilterArgs &a) {
     cfg.max_batch_reads = batch_reads + 2;
     deacon::FilterProcessor proc(index, cfg);
 
-    Queue<std::unique_ptr<Batch>> parsed(3), filtered(3);
-    // reader thread: parse into batches (pairs are never split across batches)
-    std::thread reader([&] {
-        FastxReader r1(a.input);
-        std::unique_ptr<FastxReader> r2;
-        if (paired && !paired_stdin) r2.reset(new FastxReader(a.input2));
-        uint64_t seq_no = 0;
-        bool more = true;
-        while (more) {
-            std::unique_ptr<Batch> b(new Batch());
-            b->paired = paired;
-            b->seq_no = seq_no++;
-            while (b->bases.size() < batch_bases && b->recs.size() < batch_reads) {
-                if (!r1.next(*b)) {
-                    more = false;
-                    break;
-                }
-                if (paired) {
-                    bool ok = paired_stdin ? r1.next(*b) : r2->next(*b);
-                    if (!ok) die("Paired input ended with an unpaired record");
-                    uint32_t u = (uint32_t)(b->recs.size() / 2 - 1);
-                    b->unit_id.push_back(u);
-                    b->unit_id.push_back(u);
-                }
+    // ---- stage 1: parsed batches, in input order --------------------------------------------------------------
+    // plain regular file, single input: mmap + parallel parsing of record-aligned chunks; otherwise (stdin, gzip,
+    // paired) one streaming reader thread
+    size_t n_workers = a.threads ? a.threads : std::max(1u, std::thread::hardware_concurrency());
+    n_workers = std::min<size_t>(std::max<size_t>(n_workers, 1), 64);
+    MappedFile mapped;
+    bool parallel_in = !paired && a.input != "-" && mapped.open(a.input);
+    bool fastq_in = parallel_in && mapped.data[0] == '@';
+    if (parallel_in && mapped.data[0] != '@' && mapped.data[0] != '>') die("Invalid FASTX record start: expected '>' or '@'");
+    struct Chunk {
+        size_t a, b;
+    };
+    Queue<std::unique_ptr<Batch>> parsed(4);
+    std::unique_ptr<OrderedStage> parse_stage;
+    std::thread reader;
+    if (parallel_in) {
+        const char *d = mapped.data;
+        size_t size = mapped.size;
+        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 2, [d, fastq_in](Batch &b) {
+            size_t ca = (size_t)b.offsets[0], cb = (size_t)b.seq_no;  // chunk bounds travel in the empty batch
+            b.offsets.assign(1, 0);
+            parse_mapped_chunk(d, ca, cb, fastq_in, b);
+        }));
+        reader = std::thread([&, d, size] {
+            const size_t chunk = 16u << 20;
+            size_t pos = 0;
+            while (pos < size) {
+                size_t end = pos + chunk >= size ? size : next_record_start(d, size, pos + chunk, fastq_in);
+                std::unique_ptr<Batch> b(new Batch());
+                b->offsets[0] = pos;  // see the worker lambda
+                b->seq_no = end;
+                parse_stage->push(std::move(b));
+                pos = end;
             }
-            if (!b->recs.empty()) parsed.push(std::move(b));
-        }
-        if (r2) {
-            Batch extra;
-            if (r2->next(extra)) die("Second input has more records than the first");
-        }
-        parsed.finish();
-    });
+            parse_stage->finish();
+        });
+    } else {
+        reader = std::thread([&] {
+            FastxReader r1(a.input);
+            std::unique_ptr<FastxReader> r2;
+            if (paired && !paired_stdin) r2.reset(new FastxReader(a.input2));
+            bool more = true;
+            while (more) {
+                std::unique_ptr<Batch> b(new Batch());
+                b->paired = paired;
+                while (b->bases.size() < batch_bases && b->recs.size() < batch_reads) {
+                    if (!r1.next(*b)) {
+                        more = false;
+                        break;
+                    }
+                    if (paired) {
+                        bool ok = paired_stdin ? r1.next(*b) : r2->next(*b);
+                        if (!ok) die("Paired input ended with an unpaired record");
+                        uint32_t u = (uint32_t)(b->recs.size() / 2 - 1);
+                        b->unit_id.push_back(u);
+                        b->unit_id.push_back(u);
+                    }
+                }
+                if (!b->recs.empty()) parsed.push(std::move(b));
+            }
+            if (r2) {
+                Batch extra;
+                if (r2->next(extra)) die("Second input has more records than the first");
+            }
+            parsed.finish();
+        });
+    }
+    auto next_parsed = [&](std::unique_ptr<Batch> &b) { return parallel_in ? parse_stage->pop(b) : parsed.pop(b); };
 
-    uint64_t total_seqs = 0, filtered_seqs = 0, total_bp = 0, output_bp = 0, filtered_bp = 0, out_counter = 0;
-    // writer thread: format kept records in input order
+    // ---- stage 3: format kept records on the pool, write in order -----------------------------------------------
+    const bool split_mates = (bool)out2;
+    std::vector<BatchStats> stats_by_batch;
+    std::mutex stats_m;
+    BatchStats tot;
+    OrderedStage format_stage(parallel_in ? n_workers : 2, 2 * n_workers + 2, [&](Batch &b) {
+        BatchStats st = format_batch(b, a.rename, split_mates, b.seq_no /* rename base, set by the GPU stage */);
+        std::lock_guard<std::mutex> l(stats_m);
+        tot.total_seqs += st.total_seqs;
+        tot.filtered_seqs += st.filtered_seqs;
+        tot.total_bp += st.total_bp;
+        tot.output_bp += st.output_bp;
+        tot.filtered_bp += st.filtered_bp;
+    });
     std::thread writer([&] {
         std::unique_ptr<Batch> b;
-        std::vector<char> buf1, buf2;
-        while (filtered.pop(b)) {
-            buf1.clear();
-            buf2.clear();
-            size_t per_unit = b->paired ? 2 : 1;
-            for (size_t i = 0; i < b->recs.size(); ++i) {
-                const Rec &r = b->recs[i];
-                size_t u = i / per_unit;
-                total_seqs++;
-                total_bp += r.seq_len;
-                if (!b->keep[u]) {
-                    filtered_seqs++;
-                    filtered_bp += r.seq_len;
-                    continue;
-                }
-                output_bp += r.seq_len;
-                out_counter++;
-                std::vector<char> &dst = (out2 && (i & 1)) ? buf2 : buf1;  // mate 2 to --output2
-                bool fasta = r.qual_off == UINT32_MAX;
-                dst.push_back(fasta ? '>' : '@');
-                if (a.rename) {
-                    std::string n = std::to_string(out_counter);
-                    dst.insert(dst.end(), n.begin(), n.end());
-                } else {
-                    dst.insert(dst.end(), b->text.begin() + r.id_off, b->text.begin() + r.id_off + r.id_len);
-                }
-                dst.push_back('\n');
-                dst.insert(dst.end(), b->bases.begin() + r.seq_off, b->bases.begin() + r.seq_off + r.seq_len);
-                if (fasta) {
-                    dst.push_back('\n');
-                } else {
-                    dst.insert(dst.end(), {'\n', '+', '\n'});
-                    dst.insert(dst.end(), b->text.begin() + r.qual_off, b->text.begin() + r.qual_off + r.seq_len);
-                    dst.push_back('\n');
-                }
-            }
-            out1.write(buf1);
-            if (out2) out2->write(buf2);
+        while (format_stage.pop(b)) {
+            out1.write(b->out1);
+            if (out2) out2->write(b->out2);
         }
     });
 
-    // GPU stage on the main thread
+    // ---- stage 2: the GPU, on the main thread, in input order -------------------------------------------------------
     {
         std::unique_ptr<Batch> b;
-        while (parsed.pop(b)) {
+        uint64_t written_before = 0;
+        while (next_parsed(b)) {
+            if (b->recs.empty()) continue;
             size_t n_units = b->paired ? b->recs.size() / 2 : b->recs.size();
             b->keep.assign(n_units, 0);
             b->hits.assign(n_units, 0);
@@ -432,18 +669,24 @@ int run_filter(const FilterArgs &a) {
                 for (size_t u = 0; u < n_units; ++u) {
                     if (b->paired && b->hits[u] == 0) continue;
                     const Rec &r = b->recs[u * per_unit];
-                    std::fprintf(stderr, "DEBUG: %.*s hits=%u/%u keep=%s kmers=[]\n", (int)r.id_len, b->text.data() + r.id_off,
+                    std::fprintf(stderr, "DEBUG: %.*s hits=%u/%u keep=%s kmers=[]\n", (int)r.id_len, b->chars() + r.id_off,
                                  b->hits[u], b->total[u], b->keep[u] ? "true" : "false");
                 }
             }
-            filtered.push(std::move(b));
+            b->seq_no = written_before;  // records written before this batch: base of --rename numbering
+            size_t kept_units = 0;
+            for (size_t u = 0; u < n_units; ++u) kept_units += b->keep[u] != 0;
+            written_before += kept_units * (b->paired ? 2 : 1);
+            format_stage.push(std::move(b));
         }
-        filtered.finish();
+        format_stage.finish();
     }
     reader.join();
     writer.join();
     out1.close();
     if (out2) out2->close();
+    uint64_t total_seqs = tot.total_seqs, filtered_seqs = tot.filtered_seqs, total_bp = tot.total_bp,
+             output_bp = tot.output_bp, filtered_bp = tot.filtered_bp;
 
     double secs = std::chrono::duration<double>(clock::now() - start).count();
     uint64_t seqs_out = total_seqs - filtered_seqs;
@@ -492,7 +735,7 @@ int run_index_build(const std::string &input, unsigned k, unsigned w, const std:
     while (rd.next(all)) {
         if (!quiet) {
             const Rec &r = all.recs.back();
-            std::fprintf(stderr, "  %.*s (%ubp)\n", (int)r.id_len, all.text.data() + r.id_off, r.seq_len);
+            std::fprintf(stderr, "  %.*s (%ubp)\n", (int)r.id_len, all.chars() + r.id_off, r.seq_len);
         }
     }
     dcn_index *raw = nullptr;

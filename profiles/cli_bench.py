@@ -5,7 +5,7 @@ import json, os, subprocess, sys, tempfile, time
 import numpy as np
 
 BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deacon-server_amd", "bin", "deacon-hip")
-n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 n_genome = int(sys.argv[2]) if len(sys.argv) > 2 else 64_000_000
 rng = np.random.default_rng(1)
 d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)

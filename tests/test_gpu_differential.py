@@ -1,0 +1,84 @@
+"""Randomized differential test: GPU (through the C ABI) vs the oracle over random parameters and inputs --
+k, w, thresholds, prefix lengths, unit groupings, alphabets (N runs, IUPAC, lower case, newlines), read-length
+mixes that cross every tile / flush / ring boundary.  Seeds are fixed; every case prints its parameters on failure."""
+import numpy as np
+import pytest
+
+from conftest import mutate, random_reads, revcomp
+
+pytestmark = pytest.mark.gpu
+
+KW = [(31, 15), (31, 15), (15, 11), (41, 15), (5, 5), (21, 9), (31, 1), (13, 7), (27, 19), (56, 2), (32, 16)]
+
+
+def random_case(rng, genome):
+    k, w = KW[int(rng.integers(0, len(KW)))]
+    n = int(rng.integers(1, 400))
+    style = int(rng.integers(0, 4))
+    reads = []
+    for _ in range(n):
+        if style == 0:
+            ln = int(rng.integers(0, 320))
+        elif style == 1:
+            ln = int(rng.choice([k - 1, k, k + w - 2, k + w - 1, k + w, 150, 151, 250]))
+        elif style == 2:
+            ln = int(min(40_000, max(1, rng.lognormal(6.5, 1.2))))
+        else:
+            ln = int(rng.integers(100, 3000))
+        ln = min(ln, len(genome) - 1)
+        r = rng.random()
+        if r < 0.45 and ln > 0:
+            s = int(rng.integers(0, len(genome) - ln))
+            x = mutate(rng, genome[s:s + ln], float(rng.choice([0.0, 0.01, 0.1])))
+            if rng.random() < 0.5:
+                x = revcomp(x)
+        elif r < 0.55 and ln > 0:
+            unit = random_reads(rng, 1, 1, 12)[0]
+            x = (unit * (ln // len(unit) + 1))[:ln]  # low complexity: ties, re-emitted positions
+        else:
+            x = random_reads(rng, 1, ln, ln, p_n=float(rng.choice([0.0, 0.001, 0.05])),
+                             p_lower=float(rng.choice([0.0, 0.3])),
+                             alphabet=b"ACGT" if rng.random() < 0.8 else b"ACGTNRYKMSWBDHV")[0]
+        if rng.random() < 0.02 and x:
+            x = x + b"\n"
+        reads.append(x)
+    grouping = int(rng.integers(0, 3))
+    if grouping == 0:
+        uid = None
+    elif grouping == 1:
+        uid = (np.arange(n) // 2).astype(np.uint32)
+    else:
+        uid = np.cumsum(rng.random(n) < 0.6).astype(np.uint32)
+        uid -= uid[0]
+    params = dict(abs_threshold=int(rng.choice([1, 1, 2, 2, 3, 10])), rel_threshold=float(rng.choice([0.0, 0.01, 0.01, 0.2, 0.5, 1.0])),
+                  prefix_length=int(rng.choice([0, 0, 0, 5, 60, 200, 5000])), deplete=bool(rng.integers(0, 2)))
+    return k, w, reads, uid, params
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_differential(oracle, dcn, seed, monkeypatch):
+    rng = np.random.default_rng(1000 + seed)
+    genome = random_reads(rng, 1, 60_000, 60_000)[0]
+    monkeypatch.setenv("DCN_TILE_WINDOWS", str(int(rng.choice([16, 64, 512, 512, 4096]))))
+    indexes = {}
+    for case in range(10):
+        k, w, reads, uid, params = random_case(rng, genome)
+        if (k, w) not in indexes:
+            oidx = oracle.Index.build([genome], k=k, w=w)
+            indexes[(k, w)] = (oidx, dcn.Index.from_keys(oidx.keys(), k, w))
+        oidx, gidx = indexes[(k, w)]
+        b, o = oracle.concat_reads(reads)
+        want = oracle.filter_batch(oidx, b, o, uid, **params)
+        proc = dcn.FilterProcessor(gidx, max_batch_bases=max(len(b), 1) + 64, max_batch_reads=len(reads) + 1, **params)
+        got = proc.filter_batch(b, o, uid)
+        ctx = (seed, case, k, w, len(reads), None if uid is None else "grouped", params)
+        assert got[2].tolist() == want[2].tolist(), ("total", ctx)
+        assert got[1].tolist() == want[1].tolist(), ("hits", ctx)
+        assert got[0].tolist() == want[0].tolist(), ("keep", ctx)
+        if case % 3 == 0:  # minimizer hashes / positions of every read as well
+            off, h, p = proc.minimizer_hashes_batch(b, o)
+            for r, s in enumerate(reads):
+                wh, wp = oracle.minimizer_hashes_and_positions(s, k, w, prefix_length=params["prefix_length"])
+                lo, hi = int(off[r]), int(off[r + 1])
+                assert p[lo:hi].tolist() == wp.tolist() and h[lo:hi].tolist() == wh.tolist(), ("minimizers", r, ctx)
+        proc.close()

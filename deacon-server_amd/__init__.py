@@ -1,7 +1,7 @@
 """MI355X-native read-filtering core for Deacon: HIP kernels behind a C ABI (include/deacon_hip.h) plus a thin
 host mirror of the reference's filter interface.  The directory name has a hyphen, so import it through the
 `deacon_server_amd` shim at the repository root (or importlib.import_module("deacon-server_amd"))."""
-from . import _native, distributed
+from . import _native, client, distributed, server
 from ._native import DeaconHipError, build, declared_symbols
 from .filter import (DEFAULT_KMER_LENGTH, DEFAULT_WINDOW_SIZE, FilterProcessor, Index, concat_reads,
                      get_minimizer_hashes_and_positions, paired_should_keep, unpaired_should_keep)

@@ -1,0 +1,220 @@
+"""Server surface: routes, wire shapes and decisions of src/server.rs,
+src/server_common.rs and the client half of src/remote_filter.rs.
+
+CPU tests drive the HTTP layer with the oracle standing in for the device table (the oracle is only the
+checker's backend here, never the product's); GPU tests run the real server on the device-resident index
+with the GPU client and compare every answer with the oracle."""
+import hashlib
+import json
+import urllib.error
+import urllib.request
+
+import numpy as np
+import pytest
+
+from conftest import mutate, random_reads
+
+K, W = 31, 15
+
+
+class OracleBackend:
+    def __init__(self, O, index):
+        self.O, self.index = O, index
+
+    def header(self):
+        return self.index.k, self.index.w, len(self.index)
+
+    def should_keep(self, flat, offsets, abs_threshold, rel_threshold, deplete):
+        return self.O.should_keep_hashes(self.index, flat, offsets, abs_threshold, rel_threshold, deplete)
+
+    def contains(self, flat):
+        return np.array([int(h) in self.index for h in flat], dtype=bool)
+
+
+def _workload(rng, O, n_reads=40):
+    genome = random_reads(rng, 1, 6000, 6000)[0]
+    index = O.Index.build([genome], K, W)
+    reads = []
+    for i in range(n_reads):
+        if i % 3 == 0:
+            reads.append(random_reads(rng, 1, 80, 200)[0])
+        else:
+            s = int(rng.integers(0, len(genome) - 200))
+            reads.append(mutate(rng, genome[s:s + int(rng.integers(60, 200))], 0.02))
+    reads += [b"", b"ACGT", b"A" * 31, b"ACGTN" * 30]
+    return genome, index, reads
+
+
+def _expected_unit(keys, hashes, positions, seq, k, abs_threshold, rel_threshold, deplete, debug, O, paired=False):
+    """sequence_matches / pair_matches + meets_filtering_criteria (filter_common.rs:99-198), in plain Python"""
+    seen, kmers = set(), []
+    for i, h in enumerate(hashes):
+        if h in keys and h not in seen:
+            seen.add(h)
+            if debug and i < len(positions):
+                if paired:
+                    if i < len(seq) and positions[i] + k <= len(seq[i]):
+                        kmers.append(bytes(seq[i][positions[i]:positions[i] + k]).decode())
+                else:
+                    kmers.append(bytes(seq[positions[i]:positions[i] + k]).decode())
+    keep = O.meets_filtering_criteria(len(seen), len(hashes), abs_threshold, rel_threshold, deplete)
+    return (bool(keep), len(seen), len(hashes), kmers)
+
+
+def _units_unpaired(O, reads, prefix_length=0):
+    units = []
+    for r in reads:
+        h, p = O.minimizer_hashes_and_positions(r, K, W, prefix_length)
+        eff = b"" if len(r) < K else (r[:prefix_length] if prefix_length and len(r) > prefix_length else r)
+        eff = eff[:-1] if eff.endswith(b"\n") else eff
+        units.append([[int(x) for x in h], [int(x) for x in p], list(eff)])
+    return units
+
+
+def _http(method, url, body=None, headers=None):
+    req = urllib.request.Request(url, data=body, headers=headers or {}, method=method)
+    try:
+        with urllib.request.urlopen(req) as r:
+            return r.status, r.read(), r.headers.get("Content-Type")
+    except urllib.error.HTTPError as e:
+        return e.code, e.read(), e.headers.get("Content-Type")
+
+
+@pytest.fixture()
+def oracle_server(oracle, tmp_path, dcn):
+    from deacon_server_amd import server as S
+    rng = np.random.default_rng(71)
+    genome, index, reads = _workload(rng, oracle)
+    path = tmp_path / "ref.idx"
+    index.write(str(path))
+    srv = S.DeaconServer(path, 0, host="127.0.0.1", backend=OracleBackend(oracle, index)).start()
+    yield srv, f"http://127.0.0.1:{srv.port}", index, reads, path
+    srv.shutdown()
+
+
+def test_get_routes(oracle_server):
+    srv, url, index, reads, path = oracle_server
+    st, body, ctype = _http("GET", url + "/")
+    assert st == 200
+    assert body.decode() == (f"Index loaded with {len(index)} minimizers and header: IndexHeader "
+                             f"{{ format_version: 2, kmer_length: {K}, window_size: {W} }}")
+    st, body, ctype = _http("GET", url + "/index_header")
+    assert st == 200 and ctype == "application/json"
+    assert json.loads(body) == {"format_version": 2, "kmer_length": K, "window_size": W}
+    st, body, _ = _http("GET", url + "/index_version")
+    assert st == 200
+    assert body.decode() == str(path) + "@" + hashlib.sha256(path.read_bytes()).hexdigest()
+    assert _http("GET", url + "/nope")[0] == 404
+    assert _http("GET", url + "/should_output_unpaired")[0] == 405
+    assert _http("POST", url + "/index_header", b"{}", {"Content-Type": "application/json"})[0] == 405
+
+
+def test_rejected_requests(oracle_server):
+    srv, url, index, reads, path = oracle_server
+    route = url + "/should_output_unpaired"
+    js = {"Content-Type": "application/json"}
+    good = {"input": [], "abs_threshold": 2, "rel_threshold": 0.01, "deplete": False, "kmer_length": K, "debug": False}
+    assert _http("POST", route, json.dumps(good).encode(), js)[0] == 200
+    assert _http("POST", route, json.dumps(good).encode(), {"Content-Type": "text/plain"})[0] == 415
+    assert _http("POST", route, b"{not json", js)[0] == 400
+    for field in good:
+        bad = {k: v for k, v in good.items() if k != field}
+        assert _http("POST", route, json.dumps(bad).encode(), js)[0] == 422, field
+    for field, value in (("abs_threshold", -1), ("abs_threshold", 1.5), ("kmer_length", 256), ("deplete", 1),
+                         ("input", [[[1], [0]]]), ("input", [[[-1], [0], []]]), ("input", [[["x"], [0], []]])):
+        bad = dict(good)
+        bad[field] = value
+        assert _http("POST", route, json.dumps(bad).encode(), js)[0] == 422, (field, value)
+
+
+@pytest.mark.parametrize("abs_threshold,rel_threshold,deplete,debug", [
+    (2, 0.01, False, False), (1, 0.0, True, False), (2, 0.01, True, True), (1, 0.5, False, True), (3, 1.0, False, False)])
+def test_unpaired_decisions_over_http(oracle_server, oracle, abs_threshold, rel_threshold, deplete, debug):
+    from deacon_server_amd import client as CL
+    srv, url, index, reads, path = oracle_server
+    keys = set(int(x) for x in index.keys())
+    units = _units_unpaired(oracle, reads)
+    got = CL.post_filter_request(url, False, units, abs_threshold, rel_threshold, deplete, K, debug)
+    want = [_expected_unit(keys, u[0], u[1], bytes(u[2]), K, abs_threshold, rel_threshold, deplete, debug, oracle)
+            for u in units]
+    assert got == want
+    assert any(g[0] for g in got) and not all(g[0] for g in got)
+    if debug:
+        assert any(g[3] for g in got)
+
+
+def test_paired_decisions_over_http(oracle_server, oracle):
+    from deacon_server_amd import client as CL
+    srv, url, index, reads, path = oracle_server
+    keys = set(int(x) for x in index.keys())
+    per_read = _units_unpaired(oracle, reads[:40])
+    units = []
+    for i in range(0, 40, 2):
+        a, b = per_read[i], per_read[i + 1]
+        # one case keeps per-minimizer sequences so pair_matches' `all_sequences[i]` indexing is exercised
+        seqs = [a[2], b[2]] if i == 2 else []
+        units.append([a[0] + b[0], a[1] + b[1], seqs])
+    for debug in (False, True):
+        got = CL.post_filter_request(url, True, units, 2, 0.01, False, K, debug)
+        want = [_expected_unit(keys, u[0], u[1], [bytes(s) for s in u[2]], K, 2, 0.01, False, debug, oracle, paired=True)
+                for u in units]
+        assert got == want
+
+
+# ---- GPU: the real server on the device-resident table, with the GPU client -------------------------------
+
+@pytest.fixture()
+def gpu_server(oracle, tmp_path, dcn):
+    from deacon_server_amd import server as S
+    rng = np.random.default_rng(72)
+    genome, index, reads = _workload(rng, oracle, n_reads=300)
+    path = tmp_path / "ref.idx"
+    index.write(str(path))
+    srv = S.DeaconServer(path, 0, host="127.0.0.1").start()
+    yield srv, f"http://127.0.0.1:{srv.port}", index, reads
+    srv.shutdown()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("abs_threshold,rel_threshold,deplete,prefix_length", [
+    (2, 0.01, False, 0), (1, 0.0, True, 0), (2, 0.2, False, 100), (1, 1.0, True, 0)])
+def test_gpu_client_server_unpaired(gpu_server, oracle, abs_threshold, rel_threshold, deplete, prefix_length):
+    from deacon_server_amd import client as CL
+    srv, url, index, reads = gpu_server
+    assert CL.get_server_index_header(url) == {"format_version": 2, "kmer_length": K, "window_size": W}
+    rf = CL.RemoteFilter(url, abs_threshold, rel_threshold, prefix_length, deplete)
+    got = rf.filter_reads(reads)
+    bases, offsets = oracle.concat_reads(reads)
+    keep, hits, total = oracle.filter_batch(index, bases, offsets, None, abs_threshold, rel_threshold,
+                                            prefix_length, deplete)
+    assert [(g[0], g[1], g[2]) for g in got] == [(bool(k), int(h), int(t)) for k, h, t in zip(keep, hits, total)]
+    assert all(g[3] == [] for g in got)
+    rf.close()
+
+
+@pytest.mark.gpu
+def test_gpu_client_server_paired(gpu_server, oracle):
+    from deacon_server_amd import client as CL
+    srv, url, index, reads = gpu_server
+    reads = reads[:len(reads) // 2 * 2]
+    rf = CL.RemoteFilter(url, 2, 0.01, 0, False)
+    got = rf.filter_reads(reads, paired=True)
+    bases, offsets = oracle.concat_reads(reads)
+    unit_id = (np.arange(len(reads)) // 2).astype(np.uint32)
+    keep, hits, total = oracle.filter_batch(index, bases, offsets, unit_id, 2, 0.01, 0, False)
+    assert [(g[0], g[1], g[2]) for g in got] == [(bool(k), int(h), int(t)) for k, h, t in zip(keep, hits, total)]
+    rf.close()
+
+
+@pytest.mark.gpu
+def test_gpu_server_debug_kmers(gpu_server, oracle):
+    from deacon_server_amd import client as CL
+    srv, url, index, reads = gpu_server
+    keys = set(int(x) for x in index.keys())
+    rf = CL.RemoteFilter(url, 1, 0.0, 0, False, debug=True)
+    got = rf.filter_reads(reads)
+    units = _units_unpaired(oracle, reads)
+    want = [_expected_unit(keys, u[0], u[1], bytes(u[2]), K, 1, 0.0, False, True, oracle) for u in units]
+    assert got == want
+    assert sum(len(g[3]) for g in got) > 100
+    rf.close()

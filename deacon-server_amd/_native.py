@@ -86,6 +86,8 @@ _SIGNATURES = {
     "dcn_ctx_synchronize": (C.c_int, [_vp]),
     "dcn_ctx_reserve_records": (C.c_int, [_vp, C.c_uint64]),
     "dcn_ctx_stream": (_vp, [_vp]),
+    "dcn_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(_vp)]),
+    "dcn_host_free": (None, [_vp]),
     "dcn_minimizer_hashes_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp, _vp, _vp, C.c_uint64]),
     "dcn_should_keep_hashes": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp]),
     "dcn_ctx_stats": (C.c_int, [_vp, _u64p]),

@@ -10,9 +10,13 @@
 #include "dcn_plan.h"
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #define DCN_VERSION_STRING "deacon-hip 0.1.0 (gfx950)"
@@ -520,15 +524,107 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     return DCN_OK;
 }
 
-// copy `bytes` of host memory to device through the two pinned staging buffers on the copy stream
+// A few host threads that split one large memcpy: a single core moves ~10 GB/s into the pinned staging
+// buffer, which is less than the PCIe link takes out of it.  Process-wide, created on first use;
+// DCN_HOST_THREADS sets the width (default: up to 8, 1 = plain memcpy).
+class HostCopyPool {
+  public:
+    static HostCopyPool &get() {
+        static HostCopyPool pool;
+        return pool;
+    }
+    void copy(void *dst, const void *src, size_t n) {
+        if (n_threads_ <= 1 || n < (4u << 20)) {
+            memcpy(dst, src, n);
+            return;
+        }
+        std::lock_guard<std::mutex> user(user_mu_); // one copy at a time
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            dst_ = (uint8_t *)dst;
+            src_ = (const uint8_t *)src;
+            n_ = n;
+            pending_ = n_threads_ - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        slice(0);
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [&] { return pending_ == 0; });
+    }
+    ~HostCopyPool() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+
+  private:
+    HostCopyPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int want = (int)std::min<unsigned>(8, hw ? hw : 1);
+        if (const char *e = getenv("DCN_HOST_THREADS")) want = atoi(e);
+        n_threads_ = std::max(1, std::min(want, 64));
+        for (int i = 1; i < n_threads_; ++i) workers_.emplace_back([this, i] { run(i); });
+    }
+    void slice(int i) {
+        size_t per = ((n_ / n_threads_) + 4095) & ~(size_t)4095;
+        size_t lo = std::min(n_, per * i), hi = i == n_threads_ - 1 ? n_ : std::min(n_, per * (i + 1));
+        if (hi > lo) memcpy(dst_ + lo, src_ + lo, hi - lo);
+    }
+    void run(int i) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            slice(i);
+            std::lock_guard<std::mutex> g(mu_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    int n_threads_ = 1;
+    std::vector<std::thread> workers_;
+    std::mutex mu_, user_mu_;
+    std::condition_variable cv_, done_cv_;
+    uint8_t *dst_ = nullptr;
+    const uint8_t *src_ = nullptr;
+    size_t n_ = 0;
+    int pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+
+// page-locked host memory (hipHostMalloc / hipHostRegister, e.g. from dcn_host_alloc) needs no staging
+bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc memory: not an error for us
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// copy `bytes` of host memory to device on the copy stream: directly when the source is page-locked,
+// otherwise through the two pinned staging buffers (the host fills one while the other is in flight)
 int staged_h2d(dcn_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
     const uint8_t *src = (const uint8_t *)h_src;
     uint8_t *dst = (uint8_t *)d_dst;
+    if (bytes == 0) return DCN_OK;
+    if (is_pinned_host(h_src)) {
+        DCN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        return DCN_OK;
+    }
     int which = 0;
     for (uint64_t off = 0; off < bytes; off += c->stage_bytes, which ^= 1) {
         uint64_t m = std::min<uint64_t>(c->stage_bytes, bytes - off);
         DCN_HIP(hipEventSynchronize(c->stage_free[which])); // previous copy out of this buffer finished
-        memcpy(c->h_stage[which], src + off, m);
+        HostCopyPool::get().copy(c->h_stage[which], src + off, m);
         DCN_HIP(hipMemcpyAsync(dst + off, c->h_stage[which], m, hipMemcpyHostToDevice, c->copy_stream));
         DCN_HIP(hipEventRecord(c->stage_free[which], c->copy_stream));
     }
@@ -675,6 +771,7 @@ extern "C" int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64
                                 uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
                                 uint32_t *total) {
     if (!ctx) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
+    auto t_enter = std::chrono::steady_clock::now();
     DCN_TRY(check_params(params));
     if (n_reads == 0) return DCN_OK;
     if (!offsets || !keep) return dcn_fail(DCN_ERR_ARG, "offsets/keep is NULL");
@@ -683,12 +780,19 @@ extern "C" int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64
     uint64_t n_bases = offsets[n_reads];
     if (n_bases > 0 && !bases) return dcn_fail(DCN_ERR_ARG, "bases is NULL");
     DCN_HIP(hipSetDevice(ctx->device));
+    static const bool timing = getenv("DCN_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    auto t_stage = now();
     // stage inputs on the copy stream; the compute stream waits for the last copy
     DCN_TRY(staged_h2d(ctx, ctx->d_ascii, bases, n_bases));
     DCN_TRY(staged_h2d(ctx, ctx->d_offsets, offsets, (uint64_t)(n_reads + 1) * sizeof(uint64_t)));
     if (unit_id) DCN_TRY(staged_h2d(ctx, ctx->d_unit_id, unit_id, (uint64_t)n_reads * sizeof(uint32_t)));
     DCN_HIP(hipEventRecord(ctx->copy_done, ctx->copy_stream));
     DCN_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
+    auto t_run = now();
     for (int attempt = 0;; ++attempt) {
         DCN_TRY(enqueue_batch(ctx, ctx->d_ascii, ctx->d_offsets, unit_id ? ctx->d_unit_id : nullptr, n_reads, n_bases,
                               n_units, params, ctx->d_keep, ctx->d_hits, ctx->d_total));
@@ -701,10 +805,29 @@ extern "C" int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64
         DCN_TRY(alloc_records(ctx, std::min<uint64_t>(want, 1ull << 29)));
         // (the finish kernel skips the counters of an overflowed attempt, so nothing is double counted)
     }
+    auto t_back = now();
     DCN_HIP(hipMemcpy(keep, ctx->d_keep, n_units, hipMemcpyDeviceToHost));
     if (hits) DCN_HIP(hipMemcpy(hits, ctx->d_hits, (uint64_t)n_units * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (total) DCN_HIP(hipMemcpy(total, ctx->d_total, (uint64_t)n_units * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (timing)
+        fprintf(stderr, "dcn_filter_batch: validate %.2f ms, stage+enqueue copies %.2f ms, copies drain+kernels %.2f ms, "
+                        "results back %.2f ms\n", ms(t_enter, t_stage), ms(t_stage, t_run), ms(t_run, t_back), ms(t_back, now()));
     return DCN_OK;
+}
+
+extern "C" int dcn_host_alloc(uint64_t bytes, void **out) {
+    if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, std::max<uint64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        return dcn_fail(DCN_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    return DCN_OK;
+}
+
+extern "C" void dcn_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int dcn_ctx_set_profiling(dcn_ctx *ctx, int enable) {

@@ -48,6 +48,31 @@ def concat_reads(reads):
     return bases, offsets
 
 
+class PinnedBuffer:
+    """Page-locked host memory from dcn_host_alloc, viewed as a numpy array: batches built in one go over PCIe
+    without the staging copy.  Keep the object alive while `.array` is in use."""
+
+    def __init__(self, count, dtype=np.uint8):
+        dtype = np.dtype(dtype)
+        self._p = C.c_void_p()
+        self.nbytes = int(count) * dtype.itemsize
+        N.check(N.lib().dcn_host_alloc(self.nbytes, C.byref(self._p)))
+        raw = (C.c_uint8 * max(self.nbytes, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(raw, dtype=dtype, count=int(count))
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.array = None
+            N.lib().dcn_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Index:
     """Device-resident minimizer set (stands for Arc<FxHashSet<u64>> + IndexHeader)."""
 

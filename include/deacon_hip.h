@@ -161,6 +161,12 @@ int dcn_ctx_reserve_records(dcn_ctx *ctx, uint64_t n_records);
 /* Raw HIP stream (hipStream_t) the context enqueues on, so a caller can time or order against it. */
 void *dcn_ctx_stream(dcn_ctx *ctx);
 
+/* Page-locked host memory for batch buffers.  dcn_filter_batch copies from such memory (or any memory the
+ * caller registered with hipHostRegister) straight over PCIe; pageable memory goes through the context's
+ * pinned staging buffers first.  Stands for nothing in the reference (its batches never leave the host). */
+int dcn_host_alloc(uint64_t bytes, void **out);
+void dcn_host_free(void *p);
+
 /* Minimizer hashes and positions of every read of a host batch: the (Vec<u64>, Vec<u32>) of
  * get_minimizer_hashes_and_positions (src/filter_common.rs:211-310), concatenated read by read.
  *   out_offsets  n_reads+1 entries: read r owns [out_offsets[r], out_offsets[r+1]) of the two arrays

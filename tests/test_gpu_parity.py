@@ -396,6 +396,33 @@ def test_device_resident_inputs(oracle, dcn, genome, index_pair):
 # ------------------------------------------------------------------------------------------------------
 # size-independent properties at a larger size (no oracle pass over the full input)
 # ------------------------------------------------------------------------------------------------------
+def test_page_locked_and_large_pageable_batches(oracle, dcn, genome, index_pair):
+    """dcn_filter_batch copies page-locked buffers directly and splits large pageable ones over the host
+    copy threads (several staging rounds): both must give the oracle's answers."""
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(40)
+    reads = sample_reads(rng, genome, 50_000, 140, 160) * 8  # ~60 MB: two staging rounds, above the pool threshold
+    bases, offsets = oracle.concat_reads(reads)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=len(bases), max_batch_reads=len(reads))
+    want = oracle.filter_batch(oidx, bases, offsets, threads=8)
+    got = proc.filter_batch(bases, offsets)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    pb = dcn.PinnedBuffer(len(bases), np.uint8)
+    po = dcn.PinnedBuffer(len(offsets), np.uint64)
+    pb.array[:] = bases
+    po.array[:] = offsets
+    got = proc.filter_batch(pb.array, po.array)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    # a slice of a page-locked allocation is still page-locked
+    n = 1000
+    got = proc.filter_batch(pb.array[:int(offsets[n])], po.array[:n + 1])
+    assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n])
+    pb.close()
+    po.close()
+
+
 def test_properties_at_scale(oracle, dcn, genome, index_pair):
     oidx, gidx = index_pair
     rng = np.random.default_rng(39)

@@ -33,6 +33,7 @@ K, W = 31, 15
 READ_LEN = 150
 PANHUMAN_KEYS = 409_913_780  # README.md:52 of the reference
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+SCATTER_CEILING = 46e9  # random 16-byte reads/s of a 2^31-slot table on MI355X, measured (profiles/r01_probe_patterns_17GB.txt)
 
 
 def log(*a):
@@ -391,6 +392,12 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_ms,
                 "minimizers_per_launch": n_minimizers // C,
+                # second ceiling, reported beside the contract's: every minimizer is one scattered 16-byte
+                # request, and the chip serves 46 G of those per second from a 17 GB table however they are
+                # issued (profiles/r01_probe_patterns_17GB.txt; 56 G/s from a 134 MB table, _small.txt)
+                "scattered_probes_per_s": n_minimizers / C / (scan_ms * 1e-3),
+                "scattered_ceiling_per_s": SCATTER_CEILING,
+                "frac_of_scattered_ceiling": n_minimizers / C / (scan_ms * 1e-3) / SCATTER_CEILING,
             },
             "stage_ms_per_launch": {k_: v / max(n_prof, 1) for k_, v in stage_ms.items()},
             "kept_fraction": kept / n_units,

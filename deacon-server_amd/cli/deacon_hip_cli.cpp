@@ -511,6 +511,49 @@ struct FilterArgs {
     int compression_level = 2;
 };
 
+// --debug lines of process_record / process_record_pair (src/local_filter.rs:354-363, 424-434).  Single reads list
+// the k-mer under every first occurrence of a hit hash, in read order (sequence_matches, src/filter_common.rs:
+// 143-153): positions come from dcn_minimizer_hashes_batch, membership from dcn_index_contains.  Pairs print
+// "id1/id2" only when something hit, and their k-mer list is always empty in the reference, because
+// get_paired_minimizer_hashes_and_positions never fills the sequence list pair_matches cuts from
+// (src/filter_common.rs:326-345 extends it by hashes.len() - positions.len() = 0 copies).
+void debug_lines(deacon::FilterProcessor &proc, const deacon::Index &index, const Batch &b, size_t n_units,
+                 size_t prefix_length) {
+    const char *chars = b.chars();
+    if (b.paired) {
+        for (size_t u = 0; u < n_units; ++u) {
+            if (b.hits[u] == 0) continue;
+            const Rec &r1 = b.recs[2 * u], &r2 = b.recs[2 * u + 1];
+            std::fprintf(stderr, "DEBUG: %.*s/%.*s hits=%u/%u keep=%s kmers=[]\n", (int)r1.id_len, chars + r1.id_off,
+                         (int)r2.id_len, chars + r2.id_off, b.hits[u], b.total[u], b.keep[u] ? "true" : "false");
+        }
+        return;
+    }
+    const uint32_t n_reads = (uint32_t)b.recs.size();
+    const unsigned k = index.header().kmer_length;
+    std::vector<uint64_t> off(n_reads + 1), hashes(b.bases.size() + 1);
+    std::vector<uint32_t> pos(b.bases.size() + 1);
+    deacon::check(dcn_minimizer_hashes_batch(proc.raw(), b.bases.data(), b.offsets.data(), n_reads, prefix_length, off.data(),
+                                             hashes.data(), pos.data(), hashes.size()));
+    hashes.resize(off[n_reads]);
+    std::vector<bool> member = index.contains(hashes);
+    std::string kmers;
+    std::vector<uint64_t> seen;
+    for (uint32_t i = 0; i < n_reads; ++i) {
+        const Rec &r = b.recs[i];
+        kmers.clear();
+        seen.clear();
+        for (uint64_t j = off[i]; j < off[i + 1]; ++j) {
+            if (!member[j] || std::find(seen.begin(), seen.end(), hashes[j]) != seen.end()) continue;
+            seen.push_back(hashes[j]);
+            if (!kmers.empty()) kmers += ',';
+            kmers.append(reinterpret_cast<const char *>(b.bases.data()) + r.seq_off + pos[j], k);
+        }
+        std::fprintf(stderr, "DEBUG: %.*s hits=%u/%u keep=%s kmers=[%s]\n", (int)r.id_len, chars + r.id_off, b.hits[i],
+                     b.total[i], b.keep[i] ? "true" : "false", kmers.c_str());
+    }
+}
+
 // ---- deacon filter (src/local_filter.rs:575-824) ---------------------------------------------------------------
 int run_filter(const FilterArgs &a) {
     using clock = std::chrono::steady_clock;
@@ -664,15 +707,7 @@ int run_filter(const FilterArgs &a) {
             b->total.assign(n_units, 0);
             proc.filter_batch(b->bases.data(), b->offsets.data(), b->paired ? b->unit_id.data() : nullptr,
                               (uint32_t)b->recs.size(), b->keep.data(), b->hits.data(), b->total.data());
-            if (a.debug) {  // src/local_filter.rs:354-363 (the matched k-mer strings are not reproduced)
-                size_t per_unit = b->paired ? 2 : 1;
-                for (size_t u = 0; u < n_units; ++u) {
-                    if (b->paired && b->hits[u] == 0) continue;
-                    const Rec &r = b->recs[u * per_unit];
-                    std::fprintf(stderr, "DEBUG: %.*s hits=%u/%u keep=%s kmers=[]\n", (int)r.id_len, b->chars() + r.id_off,
-                                 b->hits[u], b->total[u], b->keep[u] ? "true" : "false");
-                }
-            }
+            if (a.debug) debug_lines(proc, index, *b, n_units, a.prefix_length);
             b->seq_no = written_before;  // records written before this batch: base of --rename numbering
             size_t kept_units = 0;
             for (size_t u = 0; u < n_units; ++u) kept_units += b->keep[u] != 0;

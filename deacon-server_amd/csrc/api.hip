@@ -19,6 +19,11 @@
 #include <thread>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #define DCN_VERSION_STRING "deacon-hip 0.1.0 (gfx950)"
 
 // ----------------------------------------------------------------------------------------------------
@@ -86,13 +91,20 @@ extern "C" int dcn_index_from_keys(const uint64_t *keys, uint64_t n, uint8_t k, 
     return DCN_OK;
 }
 
+int dcn_load_index_fixed9(const char *path, int device, dcn_index **out, bool *handled); // below (needs the copy pool)
+
 extern "C" int dcn_index_from_file(const char *path, int device, dcn_index **out) {
     if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!path) return dcn_fail(DCN_ERR_ARG, "path is NULL");
+    // files whose hashes are all 9-byte varints (every hash >= 2^32: all of them, in practice) are decoded on
+    // the device while they stream in; anything else takes the host decoder below
+    bool handled = false;
+    int rc = dcn_load_index_fixed9(path, device, out, &handled);
+    if (rc != DCN_OK || handled) return rc;
     uint8_t k = 0, w = 0;
     std::vector<uint64_t> keys;
-    int rc = dcn_read_index_file(path, &k, &w, &keys);
+    rc = dcn_read_index_file(path, &k, &w, &keys);
     if (rc != DCN_OK) return rc;
     return dcn_index_from_keys(keys.data(), keys.size(), k, w, device, out);
 }
@@ -653,6 +665,123 @@ int validate_host_batch(const dcn_ctx *c, const uint64_t *offsets, const uint32_
 }
 
 } // namespace
+
+// Index file whose remaining bytes after the count are exactly 9 per hash: every hash is `0xFD + u64 LE`
+// (nothing shorter fits, 9 is the longest u64 varint), so record i is at a fixed offset.  The file is mapped,
+// copied chunk by chunk into pinned memory by the host copy threads, and decoded + inserted by
+// table_insert_varint9_kernel while the next chunk is being copied (load_minimizer_hashes, src/index.rs:80-107).
+// *handled stays false when the file is not of that shape (or cannot be mapped): the caller then runs the
+// general host decoder, which also produces the reference's error messages.
+int dcn_load_index_fixed9(const char *path, int device, dcn_index **out, bool *handled) {
+    *handled = false;
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return DCN_OK;
+    struct stat st;
+    uint8_t head[12];
+    ssize_t got = 0;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (got = pread(fd, head, sizeof head, 0)) < 4 || head[0] != 2) {
+        close(fd);
+        return DCN_OK;
+    }
+    const uint8_t k = head[1], w = head[2], b = head[3];
+    size_t len = b < 251 ? 1 : b == 0xFB ? 3 : b == 0xFC ? 5 : b == 0xFD ? 9 : 0;
+    uint64_t count = b;
+    if (len == 0 || (size_t)got < 3 + len) {
+        close(fd);
+        return DCN_OK;
+    }
+    if (len > 1) {
+        count = 0;
+        memcpy(&count, head + 4, len - 1);
+    }
+    const uint64_t pos = 3 + len, size = (uint64_t)st.st_size;
+    int ndev = 0;
+    if (count == 0 || count > (1ull << 40) || size - pos != 9 * count || check_kw(k, w) != DCN_OK ||
+        dcn_device_count(&ndev) != DCN_OK || device < 0 || device >= ndev) {
+        close(fd);
+        return DCN_OK;
+    }
+    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (map == MAP_FAILED) return DCN_OK;
+    madvise(map, size, MADV_SEQUENTIAL);
+    const uint8_t *src = (const uint8_t *)map + pos;
+
+    const uint64_t CH = std::min<uint64_t>(count, 8ull << 20); // records per chunk (72 MB)
+    const uint64_t ch_bytes = 9 * CH + 16;
+    dcn_index *idx = new (std::nothrow) dcn_index();
+    uint8_t *h_buf[2] = {nullptr, nullptr};
+    uint64_t *d_raw[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t st_ = nullptr;
+    unsigned long long *d_new = nullptr;
+    uint32_t *d_flags = nullptr; // [0] has_zero, [1] bad marker
+    int rc = idx ? DCN_OK : dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
+    auto hip_ok = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && rc == DCN_OK) rc = dcn_fail(DCN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipSuccess;
+    };
+    if (rc == DCN_OK) {
+        idx->device = device;
+        idx->k = k;
+        idx->w = w;
+        hip_ok(hipSetDevice(device), "hipSetDevice");
+    }
+    if (rc == DCN_OK) rc = dcn_table_alloc(idx, count);
+    if (rc == DCN_OK) {
+        hip_ok(hipDeviceSynchronize(), "table clear"); // the table's memset ran on the null stream
+        hip_ok(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "stream");
+        for (int i = 0; i < 2 && rc == DCN_OK; ++i) {
+            hip_ok(hipHostMalloc((void **)&h_buf[i], ch_bytes, hipHostMallocDefault), "hipHostMalloc");
+            hip_ok(hipMalloc((void **)&d_raw[i], ch_bytes), "hipMalloc");
+            hip_ok(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming), "event");
+            if (rc == DCN_OK) hip_ok(hipMemsetAsync(d_raw[i], 0, ch_bytes, st_), "memset");
+        }
+        hip_ok(hipMalloc((void **)&d_new, sizeof(unsigned long long)), "hipMalloc");
+        hip_ok(hipMalloc((void **)&d_flags, 2 * sizeof(uint32_t)), "hipMalloc");
+        if (rc == DCN_OK) {
+            hip_ok(hipMemsetAsync(d_new, 0, sizeof(unsigned long long), st_), "memset");
+            hip_ok(hipMemsetAsync(d_flags, 0, 2 * sizeof(uint32_t), st_), "memset");
+        }
+    }
+    int which = 0;
+    for (uint64_t off = 0; off < count && rc == DCN_OK; off += CH, which ^= 1) {
+        const uint64_t m = std::min<uint64_t>(CH, count - off);
+        if (!hip_ok(hipEventSynchronize(ev[which]), "event wait")) break; // the copy out of this buffer is done
+        HostCopyPool::get().copy(h_buf[which], src + 9 * off, 9 * m);
+        if (!hip_ok(hipMemcpyAsync(d_raw[which], h_buf[which], 9 * m, hipMemcpyHostToDevice, st_), "hipMemcpyAsync")) break;
+        rc = dcn_table_insert_varint9(idx, d_raw[which], m, d_new, d_flags, d_flags + 1, st_);
+        if (rc == DCN_OK) hip_ok(hipEventRecord(ev[which], st_), "event record");
+    }
+    unsigned long long h_new = 0;
+    uint32_t h_flags[2] = {0, 0};
+    if (rc == DCN_OK) {
+        hip_ok(hipStreamSynchronize(st_), "index load");
+        hip_ok(hipMemcpy(&h_new, d_new, sizeof h_new, hipMemcpyDeviceToHost), "hipMemcpy");
+        hip_ok(hipMemcpy(h_flags, d_flags, sizeof h_flags, hipMemcpyDeviceToHost), "hipMemcpy");
+    }
+    if (rc == DCN_OK && h_flags[1]) rc = dcn_fail(DCN_ERR_FORMAT, "Failed to deserialise minimizer hash");
+    munmap(map, size);
+    if (st_) hipStreamSynchronize(st_);
+    for (int i = 0; i < 2; ++i) {
+        if (h_buf[i]) hipHostFree(h_buf[i]);
+        if (d_raw[i]) hipFree(d_raw[i]);
+        if (ev[i]) hipEventDestroy(ev[i]);
+    }
+    if (d_new) hipFree(d_new);
+    if (d_flags) hipFree(d_flags);
+    if (st_) hipStreamDestroy(st_);
+    if (rc != DCN_OK) {
+        if (idx && idx->d_slots) hipFree(idx->d_slots);
+        delete idx;
+        return rc;
+    }
+    idx->n_keys = h_new;
+    idx->has_zero = h_flags[0] != 0;
+    *out = idx;
+    *handled = true;
+    return DCN_OK;
+}
 
 extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, uint32_t max_batch_reads,
                               dcn_ctx **out) {

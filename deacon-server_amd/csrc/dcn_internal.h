@@ -139,6 +139,8 @@ int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);
 int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t n, uint8_t *out);
 int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
                               hipStream_t stream);
+int dcn_table_insert_varint9(dcn_index *idx, const uint64_t *d_raw, uint64_t n, unsigned long long *d_new,
+                             uint32_t *d_zero, uint32_t *d_bad, hipStream_t stream); // 9-byte varint records
 int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity);                 // empty table for >= that many keys
 int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity);               // grow + rehash if needed
 int dcn_table_insert_dump(dcn_index *idx, const uint64_t *d_hash, const uint8_t *d_valid, const uint32_t *d_abs_pos,

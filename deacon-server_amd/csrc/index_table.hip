@@ -50,6 +50,52 @@ __global__ void table_insert_kernel(uint64_t *slots, uint32_t group_shift, uint3
     if (fresh) atomicAdd(n_new, fresh);
 }
 
+// Keys straight from the bytes of an index file whose hashes are all 9-byte varints (0xFD + u64 LE, which is
+// every hash >= 2^32): record i sits at raw[9 i].  `raw` is 8-byte aligned and padded by 16 readable bytes.
+__global__ void table_insert_varint9_kernel(uint64_t *slots, uint32_t group_shift, uint32_t group_mask,
+                                            const uint64_t *raw, uint64_t n, unsigned long long *n_new,
+                                            uint32_t *has_zero, uint32_t *bad_marker) {
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long fresh = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint64_t byte = 9 * i;
+        uint64_t w0 = raw[byte >> 3], w1 = raw[(byte >> 3) + 1];
+        uint32_t sh = (uint32_t)(byte & 7) * 8;
+        uint32_t marker = (uint32_t)(w0 >> sh) & 0xFFu;
+        // the 8 value bytes start one byte after the marker
+        uint64_t key = sh == 56 ? w1 : (w0 >> (sh + 8)) | (w1 << (56 - sh));
+        if (marker != 0xFDu) {
+            atomicExch(bad_marker, 1u);
+            continue;
+        }
+        if (key == 0) {
+            if (atomicExch(has_zero, 1u) == 0u) fresh++;
+            continue;
+        }
+        uint32_t g = dcn_group_of(key, group_shift, group_mask);
+        bool done = false;
+        while (!done) {
+            unsigned long long *grp = (unsigned long long *)(slots + (uint64_t)g * DCN_GROUP_SLOTS);
+            for (int s = 0; s < DCN_GROUP_SLOTS && !done; ++s) {
+                unsigned long long cur = __hip_atomic_load(&grp[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == key) {
+                    done = true;
+                } else if (cur == 0) {
+                    unsigned long long old = atomicCAS(&grp[s], 0ull, (unsigned long long)key);
+                    if (old == 0) {
+                        fresh++;
+                        done = true;
+                    } else if (old == key) {
+                        done = true;
+                    }
+                }
+            }
+            g = (g + 1) & group_mask;
+        }
+    }
+    if (fresh) atomicAdd(n_new, fresh);
+}
+
 __global__ void table_contains_kernel(dcn_table_view t, const uint64_t *keys, uint64_t n, uint8_t *out) {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -103,6 +149,18 @@ int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n) {
     hipFree(d_new);
     hipFree(d_zero);
     return rc;
+}
+
+// one chunk of 9-byte varint records already on the device; counters accumulate over chunks
+int dcn_table_insert_varint9(dcn_index *idx, const uint64_t *d_raw, uint64_t n, unsigned long long *d_new,
+                             uint32_t *d_zero, uint32_t *d_bad, hipStream_t stream) {
+    if (n == 0) return DCN_OK;
+    dcn_table_view v = idx->view();
+    uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(table_insert_varint9_kernel, dim3(blocks), dim3(256), 0, stream, idx->d_slots, v.group_shift,
+                       v.group_mask, d_raw, n, d_new, d_zero, d_bad);
+    DCN_HIP(hipGetLastError());
+    return DCN_OK;
 }
 
 int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t n, uint8_t *out) {

@@ -201,7 +201,10 @@ class Index:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().dor_set_free(self._h)
+            try:
+                lib().dor_set_free(self._h)
+            except TypeError:  # interpreter shutdown: module globals are already gone
+                pass
             self._h = None
 
     def __len__(self):

@@ -268,7 +268,7 @@ def test_cli_matches_oracle_on_random_reads(tmp_path, oracle, paired):
     idx = tmp_path / "g.idx"
     run("index", "build", tmp_path / "g.fa", "-o", idx, "-q")
     oidx = oracle.Index.build([genome])
-    assert oracle.Index.read(idx).keys().tolist().sort() == oidx.keys().tolist().sort()
+    assert np.array_equal(np.sort(oracle.Index.read(idx).keys()), np.sort(oidx.keys()))
     reads = []
     for i in range(6000):
         ln = int(rng.integers(25, 300))
@@ -298,3 +298,39 @@ def test_cli_matches_oracle_on_random_reads(tmp_path, oracle, paired):
     assert s["seqs_in"] == 6000 and s["seqs_out"] == len(want_ids)
     assert s["bp_out"] == int(lens[keep].sum()) and s["bp_removed"] == int(lens[~keep].sum())
     assert s["deplete"] is True and abs(s["seqs_out_proportion"] - len(want_ids) / 6000) < 1e-12
+
+
+@pytest.mark.gpu
+def test_debug_lines(tmp_path, oracle):  # src/local_filter.rs:354-363, 424-434
+    rng = np.random.default_rng(56)
+    genome = random_reads(rng, 1, 20_000, 20_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    oidx = oracle.Index.build([genome])
+    keys = set(int(x) for x in oidx.keys())
+    reads = [mutate(rng, genome[s:s + 150], 0.03) for s in range(0, 6000, 300)] + random_reads(rng, 5, 100, 150) + [b"ACGT"]
+    reads[3] = reads[3][:60] + reads[3][:60]  # repeated minimizers: listed once
+    fastq(tmp_path / "r.fq", [(f"r{i} d", r.decode()) for i, r in enumerate(reads)])
+    err = run("filter", idx, tmp_path / "r.fq", "--debug", "-p", 120).stderr.decode().splitlines()
+    lines = [l for l in err if l.startswith("DEBUG: ")]
+    assert len(lines) == len(reads)
+    for i, r in enumerate(reads):
+        h, p = oracle.minimizer_hashes_and_positions(r, 31, 15, 120)
+        seen, kmers = set(), []
+        for hv, pv in zip(h.tolist(), p.tolist()):
+            if hv in keys and hv not in seen:
+                seen.add(hv)
+                kmers.append(r[pv:pv + 31].decode())
+        keep = oracle.meets_filtering_criteria(len(seen), len(h), 2, 0.01, False)
+        assert lines[i] == (f"DEBUG: r{i} d hits={len(seen)}/{len(h)} keep={'true' if keep else 'false'} "
+                            f"kmers=[{','.join(kmers)}]"), i
+    assert any("kmers=[A" in l or "kmers=[C" in l or "kmers=[G" in l or "kmers=[T" in l for l in lines)
+    # pairs: "id1/id2", only pairs with hits, and the empty k-mer list the reference produces
+    fastq(tmp_path / "p1.fq", [(f"p{i}/1", reads[2 * i].decode()) for i in range(12)])
+    fastq(tmp_path / "p2.fq", [(f"p{i}/2", reads[2 * i + 1].decode()) for i in range(12)])
+    err = run("filter", idx, tmp_path / "p1.fq", tmp_path / "p2.fq", "--debug").stderr.decode().splitlines()
+    lines = [l for l in err if l.startswith("DEBUG: ")]
+    b, o = oracle.concat_reads(reads[:24])
+    keep, hits, total = oracle.filter_batch(oidx, b, o, (np.arange(24) // 2).astype(np.uint32))
+    want = [f"DEBUG: p{i}/1/p{i}/2 hits={hits[i]}/{total[i]} keep={'true' if keep[i] else 'false'} kmers=[]"
+            for i in range(12) if hits[i] > 0]
+    assert lines == want and 0 < len(want) < 12

@@ -108,6 +108,58 @@ def test_index_from_file(oracle, dcn, tmp_path, genome):
     assert not gidx.contains(keys ^ np.uint64(1)).all()
 
 
+def _write_index(path, keys, k=31, w=15):
+    """bincode-2 varint index file (src/index.rs:130-164), written here byte by byte"""
+    def varint(v):
+        v = int(v)
+        if v < 251:
+            return bytes([v])
+        if v <= 0xFFFF:
+            return b"\xfb" + v.to_bytes(2, "little")
+        if v <= 0xFFFFFFFF:
+            return b"\xfc" + v.to_bytes(4, "little")
+        return b"\xfd" + v.to_bytes(8, "little")
+    with open(path, "wb") as f:
+        f.write(bytes([2, k, w]) + varint(len(keys)) + b"".join(varint(x) for x in keys))
+
+
+def test_index_file_encodings(dcn, tmp_path):
+    """A9: the streaming device decoder (all hashes 9-byte varints) and the host decoder (anything else)
+    must load the same sets; several chunk shapes, duplicates, small values, broken files."""
+    rng = np.random.default_rng(77)
+    big = rng.integers(1 << 32, 1 << 63, 300_000, dtype=np.uint64) | np.uint64(1 << 63) * (rng.random(300_000) < 0.5)
+    big[1000:1100] = big[0:100]  # duplicates in the file are merged by the set
+    for n in (1, 7, 8, 9, 64, 250, 251, 70_000, 300_000):  # 251 and 70 000: longer count varints shift every record
+        path = tmp_path / f"big{n}.idx"
+        _write_index(path, big[:n])
+        idx = dcn.Index.from_file(str(path))
+        want = np.unique(big[:n])
+        assert len(idx) == len(want), n
+        assert np.array_equal(np.sort(idx.keys()), want), n
+    # small values use 1/3/5-byte varints: host decoder; 0 is a legal hash
+    mixed = np.concatenate([big[:5000], np.array([0, 1, 250, 251, 65535, 65536, (1 << 32) - 1, 1 << 32], np.uint64)])
+    path = tmp_path / "mixed.idx"
+    _write_index(path, mixed)
+    idx = dcn.Index.from_file(str(path))
+    assert np.array_equal(np.sort(idx.keys()), np.unique(mixed))
+    assert idx.contains(np.array([0, 2, 251], np.uint64)).tolist() == [True, False, True]
+    # same byte count as an all-9-byte file but one marker is not 0xFD -> rejected, not misread
+    path = tmp_path / "badmarker.idx"
+    _write_index(path, big[:1000])
+    raw = bytearray(path.read_bytes())
+    assert raw[3 + 3 + 9 * 500] == 0xFD
+    raw[3 + 3 + 9 * 500] = 0xFC
+    path.write_bytes(bytes(raw))
+    with pytest.raises(dcn.DeaconHipError):
+        dcn.Index.from_file(str(path))
+    # truncated file
+    path = tmp_path / "short.idx"
+    _write_index(path, big[:1000])
+    path.write_bytes(path.read_bytes()[:-5])
+    with pytest.raises(dcn.DeaconHipError):
+        dcn.Index.from_file(str(path))
+
+
 # ------------------------------------------------------------------------------------------------------
 # K1-K3: minimizer positions and hashes
 # ------------------------------------------------------------------------------------------------------

@@ -10,10 +10,11 @@
 //
 // Flags, defaults, stderr messages and the JSON summary follow src/main.rs:24-234, src/local_filter.rs:575-824 and
 // src/filter_common.rs:11-38 of the reference.  The per-record loop of local_filter.rs (paraseq workers calling
-// should_keep_sequence / should_keep_pair) is replaced by batches through dcn_filter_batch: a reader thread parses
-// FASTA/FASTQ (plain or gzip) into batches, the main thread runs them on the GPU, a writer thread formats the kept
-// records (format_record_to_buffer, src/local_filter.rs:60-92).  Output keeps the input order (the reference's
-// order depends on worker scheduling).  The server/client commands are not part of this path.
+// should_keep_sequence / should_keep_pair) is replaced by batches through dcn_filter_batch.  Pipeline, every stage
+// in input order: parse (mmap + worker pool for a plain file, one streaming reader for stdin / gzip / pairs; it starts
+// before the GPU is initialised) -> GPU stage (its own thread and context) -> format kept records on a pool
+// (format_record_to_buffer, src/local_filter.rs:60-92) -> one writer thread.  Output keeps the input order (the reference's depends on worker scheduling).
+// The server/client commands live in deacon-server_amd/server.py / client.py.
 // Input/output compression: gzip via zlib; zstd and xz are not available in this build.
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -22,6 +23,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -44,7 +46,8 @@ const char *VERSION = "0.1.0";
 
 [[noreturn]] void die(const std::string &msg) {
     std::fprintf(stderr, "Error: %s\n", msg.c_str());
-    std::exit(1);
+    std::fflush(nullptr);
+    _exit(1);  // callable from any pipeline thread while the others are still running
 }
 
 bool ends_with(const std::string &s, const char *suf) {
@@ -554,8 +557,23 @@ void debug_lines(deacon::FilterProcessor &proc, const deacon::Index &index, cons
     }
 }
 
+// optional stage accounting (DCN_CLI_TIMING=1): busy seconds summed over the threads of each stage
+struct StageClock {
+    std::atomic<uint64_t> ns{0};
+    struct Scope {
+        StageClock &c;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        explicit Scope(StageClock &c_) : c(c_) {}
+        ~Scope() { c.ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    };
+    double seconds() const { return ns.load() * 1e-9; }
+};
+
 // ---- deacon filter (src/local_filter.rs:575-824) ---------------------------------------------------------------
 int run_filter(const FilterArgs &a) {
+    StageClock t_parse, t_gpu, t_gpu_wait, t_format, t_write, t_push_wait;
+    double m_index = 0, m_feeder_done = 0, m_gpu_done = 0, m_written = 0;  // milestones, seconds since start
+    const bool cli_timing = std::getenv("DCN_CLI_TIMING") != nullptr;
     using clock = std::chrono::steady_clock;
     auto start = clock::now();
     bool quiet = a.quiet || a.debug;  // :581
@@ -583,11 +601,6 @@ int run_filter(const FilterArgs &a) {
         std::fprintf(stderr, "Deacon-hip v%s; mode: %s; input: %s; options: %s\n", VERSION, a.deplete ? "deplete" : "search",
                      paired_stdin ? "interleaved" : paired ? "paired" : "single", opts.c_str());
     }
-    deacon::Index index = deacon::Index::load(a.index);
-    auto hd = index.header();
-    if (!quiet)
-        std::fprintf(stderr, "Loaded index (k=%u, w=%u) in %s\n", hd.kmer_length, hd.window_size,
-                     fmt_duration(std::chrono::duration<double>(clock::now() - start).count()).c_str());
     Output out1(a.output, a.compression_level);
     std::unique_ptr<Output> out2;
     if (a.has_output2 && paired) out2.reset(new Output(a.output2, a.compression_level));
@@ -602,7 +615,8 @@ int run_filter(const FilterArgs &a) {
     cfg.deplete = a.deplete;
     cfg.max_batch_bases = batch_bases + (1 << 24);
     cfg.max_batch_reads = batch_reads + 2;
-    deacon::FilterProcessor proc(index, cfg);
+    if (const char *e = std::getenv("DCN_CLI_MAX_BATCH_READS"))  // test hook: force batches to be cut into several calls
+        cfg.max_batch_reads = (uint32_t)std::max(2, std::atoi(e));
 
     // ---- stage 1: parsed batches, in input order --------------------------------------------------------------
     // plain regular file, single input: mmap + parallel parsing of record-aligned chunks; otherwise (stdin, gzip,
@@ -622,13 +636,20 @@ int run_filter(const FilterArgs &a) {
     if (parallel_in) {
         const char *d = mapped.data;
         size_t size = mapped.size;
-        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 2, [d, fastq_in](Batch &b) {
+        // (enough chunks in flight, ~12 MB each, to keep the parsers busy while the GPU runtime starts and the index loads)
+        parse_stage.reset(new OrderedStage(n_workers, 4 * n_workers + 8, [d, fastq_in, &t_parse](Batch &b) {
+            StageClock::Scope sc(t_parse);
             size_t ca = (size_t)b.offsets[0], cb = (size_t)b.seq_no;  // chunk bounds travel in the empty batch
             b.offsets.assign(1, 0);
             parse_mapped_chunk(d, ca, cb, fastq_in, b);
         }));
         reader = std::thread([&, d, size] {
-            const size_t chunk = 16u << 20;
+            // chunks stay well under glibc's 32 MB mmap threshold: the per-batch vectors are then recycled by malloc
+            // instead of being mapped, page-faulted and unmapped every time (64 MB chunks ran 1.7x slower for that
+            // reason); small files still spread over the workers
+            size_t chunk_cap = 24u << 20;
+            if (const char *e = std::getenv("DCN_CLI_CHUNK_MB")) chunk_cap = (size_t)std::max(1, std::atoi(e)) << 20;  // tuning hook
+            const size_t chunk = std::min<size_t>(std::max<size_t>(size / (4 * n_workers), 4u << 20), chunk_cap);
             size_t pos = 0;
             while (pos < size) {
                 size_t end = pos + chunk >= size ? size : next_record_start(d, size, pos + chunk, fastq_in);
@@ -673,12 +694,27 @@ int run_filter(const FilterArgs &a) {
     }
     auto next_parsed = [&](std::unique_ptr<Batch> &b) { return parallel_in ? parse_stage->pop(b) : parsed.pop(b); };
 
+    // The parsers are already running: HIP start-up (~0.25 s) and the index load happen behind them.
+    std::unique_ptr<deacon::Index> index_holder;
+    try {
+        index_holder.reset(new deacon::Index(deacon::Index::load(a.index)));
+    } catch (const std::exception &e) {
+        die(e.what());
+    }
+    deacon::Index &index = *index_holder;
+    auto hd = index.header();
+    if (!quiet)
+        std::fprintf(stderr, "Loaded index (k=%u, w=%u) in %s\n", hd.kmer_length, hd.window_size,
+                     fmt_duration(std::chrono::duration<double>(clock::now() - start).count()).c_str());
+    m_index = std::chrono::duration<double>(clock::now() - start).count();
+
     // ---- stage 3: format kept records on the pool, write in order -----------------------------------------------
     const bool split_mates = (bool)out2;
     std::vector<BatchStats> stats_by_batch;
     std::mutex stats_m;
     BatchStats tot;
     OrderedStage format_stage(parallel_in ? n_workers : 2, 2 * n_workers + 2, [&](Batch &b) {
+        StageClock::Scope sc(t_format);
         BatchStats st = format_batch(b, a.rename, split_mates, b.seq_no /* rename base, set by the GPU stage */);
         std::lock_guard<std::mutex> l(stats_m);
         tot.total_seqs += st.total_seqs;
@@ -687,43 +723,119 @@ int run_filter(const FilterArgs &a) {
         tot.output_bp += st.output_bp;
         tot.filtered_bp += st.filtered_bp;
     });
+    // one writer: several threads pwrite()-ing one growing file serialise on its inode lock (measured slower on tmpfs)
     std::thread writer([&] {
         std::unique_ptr<Batch> b;
         while (format_stage.pop(b)) {
+            StageClock::Scope sc(t_write);
             out1.write(b->out1);
             if (out2) out2->write(b->out2);
         }
     });
 
-    // ---- stage 2: the GPU, on the main thread, in input order -------------------------------------------------------
+    // ---- stage 2: the GPU, on its own thread(s); batches leave the stage in input order and the --rename numbering
+    // is done on this thread
+    // (each thread creates its context on its first batch, ~0.1 s that overlaps the other thread and the parsers)
+    std::mutex procs_m;
+    std::vector<std::unique_ptr<deacon::FilterProcessor>> procs;  // owned here so they outlive the worker threads' use
+    size_t n_gpu_threads = 1;  // two (own context each) overlap copies with kernels but measured no faster end to end
+    if (const char *e = std::getenv("DCN_CLI_GPU_THREADS")) n_gpu_threads = std::atoi(e) == 2 ? 2 : 1;  // tuning hook
+    OrderedStage gpu_stage(n_gpu_threads, n_gpu_threads + 2, [&](Batch &b) {
+        if (b.recs.empty()) return;
+        StageClock::Scope sc(t_gpu);
+        size_t n_units = b.paired ? b.recs.size() / 2 : b.recs.size();
+        b.keep.assign(n_units, 0);
+        if (a.debug) {  // hit counts are only printed by --debug
+            b.hits.assign(n_units, 0);
+            b.total.assign(n_units, 0);
+        }
+        static thread_local deacon::FilterProcessor *p = nullptr;
+        try {
+            if (!p) {
+                std::unique_ptr<deacon::FilterProcessor> fresh(new deacon::FilterProcessor(index, cfg));
+                p = fresh.get();
+                std::lock_guard<std::mutex> l(procs_m);
+                procs.push_back(std::move(fresh));
+            }
+            // a parsed chunk normally fits one call; chunks of very short or very long records are cut at unit
+            // boundaries into calls that fit the context
+            const size_t n = b.recs.size(), per = b.paired ? 2 : 1;
+            std::vector<uint64_t> sub_off;
+            std::vector<uint32_t> sub_uid;
+            for (size_t r0 = 0; r0 < n;) {
+                size_t r1 = r0;
+                while (r1 < n && (r1 - r0) + per <= cfg.max_batch_reads && b.offsets[r1 + per] - b.offsets[r0] <= cfg.max_batch_bases)
+                    r1 += per;
+                if (r1 == r0) die("a single record is longer than the largest batch (" + std::to_string(cfg.max_batch_bases) + " bases)");
+                const size_t u0 = r0 / per;
+                const uint64_t *off = b.offsets.data();
+                const uint32_t *uid = b.paired ? b.unit_id.data() : nullptr;
+                if (r0 != 0) {  // offsets and unit ids of a later piece start from zero again
+                    sub_off.resize(r1 - r0 + 1);
+                    for (size_t r = r0; r <= r1; ++r) sub_off[r - r0] = b.offsets[r] - b.offsets[r0];
+                    off = sub_off.data();
+                    if (b.paired) {
+                        sub_uid.resize(r1 - r0);
+                        for (size_t r = r0; r < r1; ++r) sub_uid[r - r0] = b.unit_id[r] - b.unit_id[r0];
+                        uid = sub_uid.data();
+                    }
+                }
+                p->filter_batch(b.bases.data() + b.offsets[r0], off, uid, (uint32_t)(r1 - r0), b.keep.data() + u0,
+                                a.debug ? b.hits.data() + u0 : nullptr, a.debug ? b.total.data() + u0 : nullptr);
+                r0 = r1;
+            }
+        } catch (const std::exception &e) {
+            die(e.what());
+        }
+    });
+    std::unique_ptr<deacon::FilterProcessor> debug_proc;  // only --debug re-scans batches (for the k-mer strings)
+    std::thread feeder([&] {
+        std::unique_ptr<Batch> b;
+        while (next_parsed(b)) gpu_stage.push(std::move(b));
+        gpu_stage.finish();
+        m_feeder_done = std::chrono::duration<double>(clock::now() - start).count();
+    });
     {
         std::unique_ptr<Batch> b;
         uint64_t written_before = 0;
-        while (next_parsed(b)) {
+        for (;;) {
+            {
+                StageClock::Scope sc(t_gpu_wait);
+                if (!gpu_stage.pop(b)) break;
+            }
             if (b->recs.empty()) continue;
             size_t n_units = b->paired ? b->recs.size() / 2 : b->recs.size();
-            b->keep.assign(n_units, 0);
-            b->hits.assign(n_units, 0);
-            b->total.assign(n_units, 0);
-            proc.filter_batch(b->bases.data(), b->offsets.data(), b->paired ? b->unit_id.data() : nullptr,
-                              (uint32_t)b->recs.size(), b->keep.data(), b->hits.data(), b->total.data());
-            if (a.debug) debug_lines(proc, index, *b, n_units, a.prefix_length);
+            if (a.debug) {
+                if (!debug_proc) debug_proc.reset(new deacon::FilterProcessor(index, cfg));
+                debug_lines(*debug_proc, index, *b, n_units, a.prefix_length);
+            }
             b->seq_no = written_before;  // records written before this batch: base of --rename numbering
             size_t kept_units = 0;
             for (size_t u = 0; u < n_units; ++u) kept_units += b->keep[u] != 0;
             written_before += kept_units * (b->paired ? 2 : 1);
+            StageClock::Scope sc(t_push_wait);
             format_stage.push(std::move(b));
         }
         format_stage.finish();
+        m_gpu_done = std::chrono::duration<double>(clock::now() - start).count();
     }
+    feeder.join();
     reader.join();
     writer.join();
+    m_written = std::chrono::duration<double>(clock::now() - start).count();
     out1.close();
     if (out2) out2->close();
     uint64_t total_seqs = tot.total_seqs, filtered_seqs = tot.filtered_seqs, total_bp = tot.total_bp,
              output_bp = tot.output_bp, filtered_bp = tot.filtered_bp;
 
     double secs = std::chrono::duration<double>(clock::now() - start).count();
+    if (cli_timing)
+        std::fprintf(stderr, "timing: wall %.3f s; busy seconds: parse %.3f (all workers), GPU stage %.3f (main thread waited %.3f for it), "
+                             "format %.3f (all workers), write %.3f; main thread blocked pushing to format %.3f\n"
+                             "timing: milestones (s): index loaded %.3f, all input parsed+queued %.3f, "
+                             "GPU stage drained %.3f, all written %.3f\n", secs, t_parse.seconds(), t_gpu.seconds(),
+                     t_gpu_wait.seconds(), t_format.seconds(), t_write.seconds(), t_push_wait.seconds(), m_index,
+                     m_feeder_done, m_gpu_done, m_written);
     uint64_t seqs_out = total_seqs - filtered_seqs;
     auto prop = [](uint64_t x, uint64_t y) { return y ? (double)x / (double)y : 0.0; };
     if (!quiet)
@@ -753,6 +865,13 @@ int run_filter(const FilterArgs &a) {
                      (unsigned long long)(total_seqs / secs), (unsigned long long)(total_bp / secs));
         std::fclose(f);
         if (!quiet) std::fprintf(stderr, "Summary saved to \"%s\"\n", a.summary.c_str());
+    }
+    // Everything is written and closed.  Tearing the pipeline down in order (unmapping gigabytes of input, freeing
+    // every batch, destroying the device table and the HIP runtime) costs ~0.25 s and changes nothing observable:
+    // leave it to the OS unless asked (DCN_CLI_FULL_TEARDOWN, e.g. under a leak checker).
+    if (!std::getenv("DCN_CLI_FULL_TEARDOWN")) {
+        std::fflush(nullptr);
+        _exit(0);
     }
     return 0;
 }

@@ -34,12 +34,19 @@ try:
     fq = os.path.join(d, "r.fq")
     rec.tofile(fq)
     size = os.path.getsize(fq)
-    for mode, extra in (("search", []), ("deplete", ["-d"])):
+    # A/B runs on the same files: DCN_CLI_BINS = comma-separated "binary[:ENV=VAL[:ENV=VAL...]]" entries
+    bins = [b for b in os.environ.get("DCN_CLI_BINS", BIN).split(",") if b]
+    for run_no, (spec, mode, extra) in enumerate([(b, m, e) for b in bins for m, e in (("search", []), ("deplete", ["-d"]))]):
+        BIN, *envs = spec.split(":")
+        env = dict(os.environ, **dict(kv.split("=", 1) for kv in envs))
+        if len(bins) > 1:
+            print(os.path.basename(BIN), " ".join(envs), end=": ", flush=True)
         t = time.perf_counter()
-        subprocess.run([BIN, "filter", os.path.join(d, "g.idx"), fq, "-o", os.path.join(d, "out.fq"), "-s",
-                        os.path.join(d, "s.json"), "-q", *extra], check=True)
+        subprocess.run([BIN, "filter", os.path.join(d, "g.idx"), fq, "-o", os.path.join(d, f"out_{run_no}.fq"), "-s",
+                        os.path.join(d, "s.json"), "-q", *extra], check=True, env=env)
         dt = time.perf_counter() - t
         s = json.load(open(os.path.join(d, "s.json")))
+        os.unlink(os.path.join(d, f"out_{run_no}.fq"))
         print(f"filter CLI ({mode}): {n_reads} x {L} bp FASTQ ({size/1e9:.2f} GB) in {dt:.2f} s wall; summary: "
               f"{s['bp_per_second']/1e6:.0f} Mbp/s incl. index load, kept {s['seqs_out']}/{s['seqs_in']}; "
               f"{size/dt/1e9:.2f} GB/s of FASTQ")

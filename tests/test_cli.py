@@ -334,3 +334,35 @@ def test_debug_lines(tmp_path, oracle):  # src/local_filter.rs:354-363, 424-434
     want = [f"DEBUG: p{i}/1/p{i}/2 hits={hits[i]}/{total[i]} keep={'true' if keep[i] else 'false'} kmers=[]"
             for i in range(12) if hits[i] > 0]
     assert lines == want and 0 < len(want) < 12
+
+
+@gpu
+@pytest.mark.parametrize("paired", [False, True])
+def test_batches_cut_into_several_calls(tmp_path, oracle, paired, monkeypatch):
+    """A parsed chunk that exceeds the context (very short records) is filtered in several calls with rebased
+    offsets / unit ids; forced here with a tiny per-call read limit."""
+    rng = np.random.default_rng(57)
+    genome = random_reads(rng, 1, 30_000, 30_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    oidx = oracle.Index.build([genome])
+    reads = []
+    for i in range(5000):
+        ln = int(rng.integers(20, 200))
+        s = int(rng.integers(0, len(genome) - ln))
+        reads.append(mutate(rng, genome[s:s + ln], 0.02) if i % 2 else random_reads(rng, 1, ln, ln)[0])
+    b, o = oracle.concat_reads(reads)
+    monkeypatch.setenv("DCN_CLI_MAX_BATCH_READS", "338")
+    if paired:
+        fastq(tmp_path / "r1.fq", [(f"r{i}/1", reads[2 * i].decode()) for i in range(2500)])
+        fastq(tmp_path / "r2.fq", [(f"r{i}/2", reads[2 * i + 1].decode()) for i in range(2500)])
+        out = run("filter", idx, tmp_path / "r1.fq", tmp_path / "r2.fq", "-R").stdout.decode()
+        keep, _, _ = oracle.filter_batch(oidx, b, o, (np.arange(5000) // 2).astype(np.uint32))
+        want = [reads[2 * i + m].decode() for i in range(2500) if keep[i] for m in (0, 1)]
+    else:
+        fastq(tmp_path / "r.fq", [(f"r{i}", r.decode()) for i, r in enumerate(reads)])
+        out = run("filter", idx, tmp_path / "r.fq", "-R").stdout.decode()
+        keep, _, _ = oracle.filter_batch(oidx, b, o)
+        want = [r.decode() for r, k_ in zip(reads, keep) if k_]
+    lines = out.split("\n")
+    assert lines[1::4][:len(want)] == want and len([l for l in lines[1::4] if l]) == len(want)
+    assert [l for l in lines[0::4] if l] == [f"@{i + 1}" for i in range(len(want))]  # --rename numbers across calls

@@ -462,6 +462,18 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     sa.abs_threshold = params->abs_threshold;
     sa.rel_threshold = params->rel_threshold;
     sa.deplete = params->deplete;
+    // decisions only: largest list length whose required hits still equal abs_threshold (dcn_required_hits is
+    // monotone in the total); the scan kernel's lanes then stop at abs_threshold distinct hits (scan.hip)
+    sa.early_out_max_items = 0;
+    if (!d_hits && !d_total && params->abs_threshold >= 1 && params->abs_threshold <= 4 && !getenv("DCN_NO_EARLY_OUT")) {
+        uint32_t lo = 0, hi = 65535; // required(lo) == abs always holds for lo = 0
+        while (lo < hi) {
+            uint32_t mid = (lo + hi + 1) / 2;
+            if (dcn_required_hits(params->abs_threshold, params->rel_threshold, mid) == params->abs_threshold) lo = mid;
+            else hi = mid - 1;
+        }
+        sa.early_out_max_items = lo;
+    }
     sa.keep = d_keep;
     sa.hits = d_hits;
     sa.total = d_total;
@@ -923,8 +935,10 @@ extern "C" int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64
     DCN_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
     auto t_run = now();
     for (int attempt = 0;; ++attempt) {
+        // without hit counts / totals the kernels only have to fix the decisions (early-out, see enqueue_batch)
         DCN_TRY(enqueue_batch(ctx, ctx->d_ascii, ctx->d_offsets, unit_id ? ctx->d_unit_id : nullptr, n_reads, n_bases,
-                              n_units, params, ctx->d_keep, ctx->d_hits, ctx->d_total));
+                              n_units, params, ctx->d_keep, (hits || total) ? ctx->d_hits : nullptr,
+                              (hits || total) ? ctx->d_total : nullptr));
         uint64_t need = 0;
         int rc = sync_and_check(ctx, &need);
         if (rc == DCN_OK) break;

@@ -111,6 +111,10 @@ struct dcn_scan_args {
     uint64_t abs_threshold;
     double rel_threshold;
     uint32_t deplete;
+    // decisions only (caller takes neither hit counts nor totals): a tile that is a whole unit with at most this many
+    // list entries has required hits == abs_threshold whatever its valid-minimizer total is, so its lane may stop
+    // probing at abs_threshold distinct hits.  0 = always count everything.
+    uint32_t early_out_max_items;
     // outputs for units resolved inside one wave
     uint8_t *keep;
     uint32_t *hits, *total;

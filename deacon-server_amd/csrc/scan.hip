@@ -88,7 +88,9 @@ struct IntTag {
 #endif
 
 // W > 0: window size known at compile time, ring in registers.  W == 0: runtime w, ring in dynamic LDS.
-template <int W, bool K128, bool DUMP>
+// FAST: the decisions-only instantiation (a.early_out_max_items != 0), kept apart so that the counting kernel's
+// register allocation does not carry the early-out path
+template <int W, bool K128, bool DUMP, bool FAST>
 __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_args a) {
     __shared__ WaveShared sh;
     extern __shared__ uint2 dyn_ring[]; // only for W == 0: [w][64] (lkey, rkey)
@@ -562,6 +564,121 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
             if (__any(cnt > DCN_LCAP - STEP)) flush(IntTag<1>{}, false);
         }
     }
+    // Decision-only fast path (a.early_out_max_items != 0: the caller reads neither hit counts nor totals).  When every
+    // tile of the wave is a whole unit of its own, never flushed mid-scan, and short enough that its required hits
+    // equal abs_threshold for any number of valid minimizers, each lane walks ITS OWN list (no flattening) and stops
+    // at abs_threshold distinct hits: the decision is already fixed (hits >= required, or for --deplete its negation),
+    // and the minimizers it did not look at cannot change it.  Reads from the indexed genome stop after their first
+    // abs_threshold minimizers; reads without hits are probed in full, exactly as below.
+    if (FAST && !DUMP && !go_global) {
+        const uint32_t skip0 = (first_pending && cnt > 0) ? 1u : 0u;
+        const uint32_t cnt_eff = cnt - skip0;
+        const bool own = !have_tile || (head && sh.local[uslot] && cnt_eff <= a.early_out_max_items);
+        if (__all(own)) {
+            const uint32_t need = (uint32_t)a.abs_threshold; // 1..4 (host side): need-1 earlier hits to remember
+            uint64_t seen0 = 0, seen1 = 0, seen2 = 0;
+            uint32_t nh = 0;
+            // one minimizer at base position p: mask test, canonical k-mer, XXH3, set probe
+            auto probe_item = [&](uint64_t p, bool actv, uint64_t &hash) -> bool {
+                bool hit = false;
+                hash = 0;
+                if (actv) {
+                    const uint32_t *mp = a.invmask + (p >> 5);
+                    const uint32_t *pp = packed + (p >> 4);
+                    const uint32_t m0 = mp[0], m1 = mp[1], m2 = mp[2];
+                    uint32_t pw[K128 ? 5 : 3];
+#pragma unroll
+                    for (int q = 0; q < (K128 ? 5 : 3); ++q) pw[q] = pp[q];
+                    const uint32_t msh = (uint32_t)(p & 31);
+                    const uint64_t mbits = ((uint64_t)__funnelshift_r(m1, m2, msh) << 32) | __funnelshift_r(m0, m1, msh);
+                    const bool valid = (mbits & ((~0ull) >> (64 - k))) == 0; // src/filter_common.rs:275-286
+                    const uint32_t psh = (uint32_t)(p & 15) * 2;
+                    const uint64_t lo64 = ((uint64_t)__funnelshift_r(pw[1], pw[2], psh) << 32) | __funnelshift_r(pw[0], pw[1], psh);
+                    if constexpr (K128) {
+                        const uint64_t hi64 = ((uint64_t)__funnelshift_r(pw[3], pw[4], psh) << 32) | __funnelshift_r(pw[2], pw[3], psh);
+                        hash = dcn_kmer_hash128_bits(lo64, hi64, k);
+                    } else {
+                        hash = dcn_kmer_hash64_bits(lo64, k);
+                    }
+                    if (valid) {
+                        if (hash == 0) {
+                            hit = a.table.has_zero != 0;
+                        } else {
+                            uint32_t grp = dcn_group_of(hash, a.table.group_shift, a.table.group_mask);
+                            int r = dcn_group_resolve(dcn_load_group(a.table, grp), hash);
+                            while (r < 0) {
+                                grp = (grp + 1) & a.table.group_mask;
+                                r = dcn_group_resolve(dcn_load_group(a.table, grp), hash);
+                            }
+                            hit = r == 1;
+                        }
+                    }
+                }
+                return hit;
+            };
+            auto note_hit = [&](uint64_t hash) { // this lane's unit has a hit on `hash`: count it if it is new
+                const bool dup = (nh > 0 && hash == seen0) | (nh > 1 && hash == seen1) | (nh > 2 && hash == seen2);
+                if (!dup) {
+                    seen2 = nh == 2 ? hash : seen2;
+                    seen1 = nh == 1 ? hash : seen1;
+                    seen0 = nh == 0 ? hash : seen0;
+                    ++nh;
+                }
+            };
+            // rounds 0 .. R1-1: lane = its own list.  Reads from the indexed genome are decided here.
+            const uint32_t maxc = wave_max_u32(cnt_eff);
+            const uint32_t R1 = min(need + 2u, maxc);
+            for (uint32_t j = 0; j < R1; ++j) {
+                const bool actv = j < cnt_eff && nh < need;
+                if (!__any(actv)) break;
+                uint64_t hash;
+                const uint32_t rel = sh.list[(actv ? j : 0u) + skip0][lane];
+                if (probe_item((uint64_t)(s + rel), actv, hash)) note_hit(hash);
+            }
+            // the rest: the undecided lanes' remaining entries, flattened over the wave so that no lane idles
+            const uint32_t rem = (nh < need && cnt_eff > R1) ? cnt_eff - R1 : 0u;
+            const uint32_t incl = wave_inclusive_scan_u32(rem, lane);
+            const uint32_t M = __shfl(incl, 63, 64);
+            if (M) {
+                sh.start[lane] = (uint16_t)(incl - rem);
+                if (lane == 63) sh.start[64] = (uint16_t)M;
+                __syncthreads();
+                for (uint32_t E = 0; E < M; E += DCN_WAVE) {
+                    const uint32_t e = E + lane;
+                    const bool act = e < M;
+                    uint32_t lo = 0, hi = 63; // owner = largest lane whose range starts at or before e
+#pragma unroll
+                    for (int it = 0; it < 6; ++it) {
+                        const uint32_t mid = (lo + hi + 1) >> 1;
+                        const bool le = sh.start[mid] <= e;
+                        lo = le ? mid : lo;
+                        hi = le ? hi : mid - 1;
+                    }
+                    const uint32_t idx = act ? e - sh.start[lo] + R1 : 0u;
+                    const uint32_t o_skip = __shfl(skip0, lo, 64);
+                    const uint32_t o_nh = __shfl(nh, lo, 64);
+                    const long long o_s = __shfl((long long)s, lo, 64);
+                    const uint32_t rel = sh.list[idx + o_skip][lo];
+                    uint64_t hash;
+                    const bool hit = probe_item((uint64_t)(o_s + rel), act && o_nh < need, hash);
+                    // hand each hit to its owner lane, one at a time (rare for reads that are not from the index)
+                    unsigned long long hb = __ballot(hit);
+                    while (hb) {
+                        const int src = __ffsll((long long)hb) - 1;
+                        hb &= hb - 1;
+                        const uint64_t h = (uint64_t)__shfl((long long)hash, src, 64);
+                        const uint32_t o = __shfl(lo, src, 64);
+                        if ((uint32_t)lane == o && nh < need) note_hit(h);
+                    }
+                }
+            }
+            if (have_tile) {
+                a.keep[t.unit] = (a.deplete ? nh < need : nh >= need) ? 1 : 0;
+                a.unit_state[t.unit] = 1;
+            }
+            return;
+        }
+    }
     flush(IntTag<DCN_U_FINAL>{}, true);
     if (DUMP) {
         if (have_tile) a.dump_count[tile_idx] = emitted_before;
@@ -585,9 +702,9 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
 
 template <int W>
 int launch_w(const dcn_scan_args &args, uint32_t blocks, bool dump, bool k128, size_t dyn, hipStream_t stream) {
-#define DCN_LAUNCH(K128_, DUMP_)                                                                      \
+#define DCN_LAUNCH(K128_, DUMP_, FAST_)                                                               \
     do {                                                                                              \
-        auto kern = scan_kernel<W, K128_, DUMP_>;                                                     \
+        auto kern = scan_kernel<W, K128_, DUMP_, FAST_>;                                              \
         if (dyn > 0) {                                                                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
@@ -595,12 +712,15 @@ int launch_w(const dcn_scan_args &args, uint32_t blocks, bool dump, bool k128, s
         }                                                                                             \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(DCN_WAVE), dyn, stream, args);                    \
     } while (0)
+    const bool fast = !dump && args.early_out_max_items != 0;
     if (k128) {
-        if (dump) DCN_LAUNCH(true, true);
-        else DCN_LAUNCH(true, false);
+        if (dump) DCN_LAUNCH(true, true, false);
+        else if (fast) DCN_LAUNCH(true, false, true);
+        else DCN_LAUNCH(true, false, false);
     } else {
-        if (dump) DCN_LAUNCH(false, true);
-        else DCN_LAUNCH(false, false);
+        if (dump) DCN_LAUNCH(false, true, false);
+        else if (fast) DCN_LAUNCH(false, false, true);
+        else DCN_LAUNCH(false, false, false);
     }
 #undef DCN_LAUNCH
     DCN_HIP(hipGetLastError());

@@ -179,8 +179,10 @@ class FilterProcessor:
         return Params(self.abs_threshold, self.rel_threshold, self.prefix_length, 1 if self.deplete else 0, 0)
 
     # -- the batch seam ---------------------------------------------------------------------------------
-    def filter_batch(self, bases, offsets, unit_id=None):
-        """bases: concatenated ASCII; offsets[n_reads+1]; unit_id groups mates -> (keep bool[], hits, total)."""
+    def filter_batch(self, bases, offsets, unit_id=None, counts=True):
+        """bases: concatenated ASCII; offsets[n_reads+1]; unit_id groups mates -> (keep bool[], hits, total).
+        counts=False asks for the decisions only (returns just keep): the kernels may then stop probing a read once
+        its decision is fixed, which is what `deacon filter` needs outside --debug."""
         bases = _as_u8(bases)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n_reads = len(offsets) - 1
@@ -190,9 +192,13 @@ class FilterProcessor:
         else:
             n_units = n_reads
         keep = np.zeros(max(n_units, 1), np.uint8)
+        p = self._params()
+        if not counts:
+            N.check(N.lib().dcn_filter_batch(self._h, _ptr(bases) if len(bases) else None, _ptr(offsets),
+                                             _ptr(unit_id), n_reads, C.byref(p), _ptr(keep), None, None))
+            return keep[:n_units].astype(bool)
         hits = np.zeros(max(n_units, 1), np.uint32)
         total = np.zeros(max(n_units, 1), np.uint32)
-        p = self._params()
         N.check(N.lib().dcn_filter_batch(self._h, _ptr(bases) if len(bases) else None, _ptr(offsets),
                                          _ptr(unit_id), n_reads, C.byref(p), _ptr(keep), _ptr(hits), _ptr(total)))
         return keep[:n_units].astype(bool), hits[:n_units], total[:n_units]

@@ -137,6 +137,10 @@ void dcn_ctx_destroy(dcn_ctx *ctx);
  *   hits     out (may be NULL), distinct minimizer hits per unit
  *   total    out (may be NULL), minimizer count per unit (duplicates included) -- the
  *            (bool, usize, usize) of should_keep_*
+ * With hits == NULL and total == NULL only the decisions are produced, which is all `deacon filter` consumes
+ * outside --debug (src/local_filter.rs:350-371): the kernels may then stop probing a unit as soon as its
+ * decision is fixed (abs_threshold distinct hits reached while the relative threshold cannot ask for more).
+ * keep and the six counters are identical in both forms.
  * Blocking; internally pinned staging + hipMemcpyAsync on a side stream overlapped with the kernels. */
 int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
                      uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,

@@ -75,6 +75,7 @@ def test_differential(oracle, dcn, seed, monkeypatch):
         assert got[2].tolist() == want[2].tolist(), ("total", ctx)
         assert got[1].tolist() == want[1].tolist(), ("hits", ctx)
         assert got[0].tolist() == want[0].tolist(), ("keep", ctx)
+        assert proc.filter_batch(b, o, uid, counts=False).tolist() == want[0].tolist(), ("keep, decisions only", ctx)
         if case % 3 == 0:  # minimizer hashes / positions of every read as well
             off, h, p = proc.minimizer_hashes_batch(b, o)
             for r, s in enumerate(reads):

@@ -36,6 +36,14 @@ def check_batch(oracle, proc, oidx, reads, unit_id=None, **kw):
     assert got[2].tolist() == want[2].tolist(), "total minimizers differ"
     assert got[1].tolist() == want[1].tolist(), "distinct hit counts differ"
     assert got[0].tolist() == want[0].tolist(), "keep decisions differ"
+    # decisions-only mode (lanes stop probing once a read's decision is fixed): same decisions, same counters
+    s0 = proc.stats()
+    keep_only = proc.filter_batch(b, o, unit_id, counts=False)
+    assert keep_only.tolist() == want[0].tolist(), "decisions-only mode differs"
+    s1 = proc.stats()
+    proc.filter_batch(b, o, unit_id)
+    s2 = proc.stats()
+    assert {n: s1[n] - s0[n] for n in s0} == {n: s2[n] - s1[n] for n in s0}, "counters differ between the two modes"
     return got
 
 
@@ -340,7 +348,7 @@ def test_record_scratch_grows(oracle, dcn, genome, index_pair):
     keep, hits, total = check_batch(oracle, proc, oidx, reads)
     assert hits.sum() > (1 << 16) // 8
     s = proc.stats()
-    assert s["total_seqs"] == len(reads)  # the overflowed attempt was not counted twice
+    assert s["total_seqs"] == 3 * len(reads)  # check_batch makes three calls; the overflowed attempt is not counted
 
 
 def test_empty_and_ragged_batches(oracle, dcn, index_pair):
@@ -473,6 +481,32 @@ def test_page_locked_and_large_pageable_batches(oracle, dcn, genome, index_pair)
     assert np.array_equal(got[0], want[0][:n]) and np.array_equal(got[1], want[1][:n])
     pb.close()
     po.close()
+
+
+@pytest.mark.parametrize("abs_t,rel_t,deplete", [(1, 0.0, False), (2, 0.01, False), (2, 0.01, True), (3, 0.05, True),
+                                                 (4, 0.0, False), (5, 0.0, False), (2, 0.2, False), (1, 1.0, True)])
+def test_decisions_only_mode(oracle, dcn, genome, index_pair, abs_t, rel_t, deplete):
+    """dcn_filter_batch with hits = total = NULL: the early-out path (abs 1..4 and a relative threshold that cannot
+    raise the requirement for a list of that length) and its fall-backs (abs 5, large -r, reads with N runs whose
+    valid-minimizer total is smaller than the list, repeats whose hits are not distinct, pairs, long reads)."""
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(41)
+    reads = sample_reads(rng, genome, 6000, 31, 300, p_n=0.01)
+    rep = genome[7000:7040]
+    reads[10] = rep * 5                      # the same few minimizers again and again: distinct hits stay low
+    reads[11] = rep + b"N" * 40 + rep        # hits on both sides of an invalid stretch
+    reads[12] = genome[9000:9045]            # exactly one window
+    reads[13] = b"N" * 100
+    reads[14] = genome[100:5100]             # long read: several tiles, exact path
+    proc = dcn.FilterProcessor(gidx, abs_threshold=abs_t, rel_threshold=rel_t, deplete=deplete,
+                               max_batch_bases=1 << 22, max_batch_reads=1 << 13)
+    b, o = oracle.concat_reads(reads)
+    want = oracle.filter_batch(oidx, b, o, None, abs_t, rel_t, 0, deplete, threads=4)[0]
+    assert proc.filter_batch(b, o, counts=False).tolist() == want.tolist()
+    assert 0 < want.sum() < len(want)
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32)
+    want = oracle.filter_batch(oidx, b, o, uid, abs_t, rel_t, 0, deplete, threads=4)[0]
+    assert proc.filter_batch(b, o, uid, counts=False).tolist() == want.tolist()
 
 
 def test_properties_at_scale(oracle, dcn, genome, index_pair):

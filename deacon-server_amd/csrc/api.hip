@@ -473,6 +473,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
             else hi = mid - 1;
         }
         sa.early_out_max_items = lo;
+        sa.early_out_pairs = getenv("DCN_NO_EARLY_OUT_PAIRS") ? 0u : 1u;
     }
     sa.keep = d_keep;
     sa.hits = d_hits;

@@ -115,6 +115,7 @@ struct dcn_scan_args {
     // list entries has required hits == abs_threshold whatever its valid-minimizer total is, so its lane may stop
     // probing at abs_threshold distinct hits.  0 = always count everything.
     uint32_t early_out_max_items;
+    uint32_t early_out_pairs; // 1: two-tile units in adjacent lanes may take that path too
     // outputs for units resolved inside one wave
     uint8_t *keep;
     uint32_t *hits, *total;

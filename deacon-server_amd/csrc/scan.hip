@@ -569,11 +569,23 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
     // equal abs_threshold for any number of valid minimizers, each lane walks ITS OWN list (no flattening) and stops
     // at abs_threshold distinct hits: the decision is already fixed (hits >= required, or for --deplete its negation),
     // and the minimizers it did not look at cannot change it.  Reads from the indexed genome stop after their first
-    // abs_threshold minimizers; reads without hits are probed in full, exactly as below.
+    // abs_threshold minimizers; reads without hits are probed in full, exactly as below.  A pair whose two tiles sit
+    // in adjacent lanes works the same way, both lanes holding the pair's state.
     if (FAST && !DUMP && !go_global) {
         const uint32_t skip0 = (first_pending && cnt > 0) ? 1u : 0u;
         const uint32_t cnt_eff = cnt - skip0;
-        const bool own = !have_tile || (head && sh.local[uslot] && cnt_eff <= a.early_out_max_items);
+        // units of one tile, or of two adjacent tiles (a pair): the two lanes keep identical copies of the unit's state
+        // (cross-lane operations stay outside conditional expressions: inside a short-circuit they would only see
+        // the lanes that got that far)
+        const unsigned long long tile_mask = __ballot(have_tile);
+        const unsigned long long up1 = lane < 63 ? 1ull << (lane + 1) : 0ull, down1 = lane > 0 ? 1ull << (lane - 1) : 0ull;
+        const bool prev_head = (head_mask & down1) != 0;
+        const bool next_mate = (tile_mask & up1) != 0 && (head_mask & up1) == 0;
+        const uint32_t uh = head ? (uint32_t)lane : (uint32_t)lane - 1u;                          // the unit's first lane
+        const uint32_t partner = head ? (next_mate ? (uint32_t)lane + 1u : (uint32_t)lane) : (uint32_t)lane - 1u;
+        const uint32_t partner_cnt = __shfl(cnt_eff, partner, 64);
+        const uint32_t cnt_unit = cnt_eff + (partner != (uint32_t)lane ? partner_cnt : 0u);
+        const bool own = !have_tile || ((head || (prev_head && a.early_out_pairs)) && sh.local[uslot] && cnt_unit <= a.early_out_max_items);
         if (__all(own)) {
             const uint32_t need = (uint32_t)a.abs_threshold; // 1..4 (host side): need-1 earlier hits to remember
             uint64_t seen0 = 0, seen1 = 0, seen2 = 0;
@@ -633,7 +645,15 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                 if (!__any(actv)) break;
                 uint64_t hash;
                 const uint32_t rel = sh.list[(actv ? j : 0u) + skip0][lane];
-                if (probe_item((uint64_t)(s + rel), actv, hash)) note_hit(hash);
+                const bool hit = probe_item((uint64_t)(s + rel), actv, hash);
+                // both lanes of a pair apply the unit's hits in the same order (first mate's, then second mate's)
+                const bool p_hit = __shfl((int)hit, partner, 64) != 0;
+                const uint64_t p_hash = (uint64_t)__shfl((long long)hash, partner, 64);
+                const bool paired_lane = partner != (uint32_t)lane;
+                const bool h1 = head ? hit : p_hit, h2 = head ? (paired_lane && p_hit) : hit;
+                const uint64_t v1 = head ? hash : p_hash, v2 = head ? p_hash : hash;
+                if (h1 && nh < need) note_hit(v1);
+                if (h2 && nh < need) note_hit(v2);
             }
             // the rest: the undecided lanes' remaining entries, flattened over the wave so that no lane idles
             const uint32_t rem = (nh < need && cnt_eff > R1) ? cnt_eff - R1 : 0u;
@@ -668,11 +688,12 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                         hb &= hb - 1;
                         const uint64_t h = (uint64_t)__shfl((long long)hash, src, 64);
                         const uint32_t o = __shfl(lo, src, 64);
-                        if ((uint32_t)lane == o && nh < need) note_hit(h);
+                        const uint32_t o_uh = __shfl(uh, o, 64);
+                        if (uh == o_uh && nh < need) note_hit(h); // every lane of the owner's unit
                     }
                 }
             }
-            if (have_tile) {
+            if (have_tile && head) {
                 a.keep[t.unit] = (a.deplete ? nh < need : nh >= need) ? 1 : 0;
                 a.unit_state[t.unit] = 1;
             }

@@ -266,10 +266,9 @@ struct dcn_ctx {
     // packed stream
     uint32_t *d_packed = nullptr, *d_invmask = nullptr; // allocations (views skip DCN_FRONT_PAD words)
     // plan
-    uint32_t *d_read_windows = nullptr, *d_read_tiles = nullptr, *d_read_tile_first = nullptr;
+    uint32_t *d_read_tiles = nullptr, *d_read_tile_first = nullptr;
     uint32_t *d_unit_first_read = nullptr, *d_unit_tile_first = nullptr, *d_unit_tile_count = nullptr;
     dcn_tile *d_tiles = nullptr;
-    uint32_t *d_scan_tmp = nullptr;
     // per-unit results / scratch
     uint8_t *d_keep = nullptr, *d_unit_state = nullptr;
     uint32_t *d_hits = nullptr, *d_total = nullptr;
@@ -344,9 +343,9 @@ void free_ctx(dcn_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
-    void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask, c->d_read_windows,
+    void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask,
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
-                   c->d_scan_tmp, c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
+                   c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
                    c->d_set_off, c->d_rec_unit, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
     for (void *p : dev)
@@ -434,9 +433,8 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     pa.w = idx->w;
     pa.prefix_length = params->prefix_length;
     pa.tile_windows = c->tile_windows;
-    pa.read_windows = c->d_read_windows;
-    pa.read_tiles = c->d_read_tiles;
-    pa.read_tile_first = c->d_read_tile_first;
+    pa.read_tiles = nullptr; // per-read tile ranges are only needed by the minimizer dump
+    pa.read_tile_first = nullptr;
     pa.unit_first_read = c->d_unit_first_read;
     pa.unit_tile_first = c->d_unit_tile_first;
     pa.unit_tile_count = c->d_unit_tile_count;
@@ -502,7 +500,8 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     da.set_capacity = 4 * c->rec_capacity + 64;
     da.n_units = n_units;
     da.status = c->d_status;
-    DCN_TRY(dcn_launch_distinct(da, c->d_caps, c->d_scan_tmp, st));
+    da.caps = c->d_caps;
+    DCN_TRY(dcn_launch_distinct(da, st));
     DCN_PROF_MARK(DCN_STAGE_DISTINCT);
 
     dcn_finish_args fa;
@@ -839,14 +838,12 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_unit_id, MR, "unit_id");
     A(d_packed, packed_words(max_batch_bases), "packed");
     A(d_invmask, mask_words(max_batch_bases), "invmask");
-    A(d_read_windows, MR, "read_windows");
     A(d_read_tiles, MR, "read_tiles");
     A(d_read_tile_first, MR + 1, "read_tile_first");
     A(d_unit_first_read, MR + 1, "unit_first_read");
     A(d_unit_tile_first, MR + 1, "unit_tile_first");
     A(d_unit_tile_count, MR + 1, "unit_tile_count");
     A(d_tiles, mt, "tiles");
-    A(d_scan_tmp, dcn_scan_tmp_words(max_batch_reads) + 8, "scan_tmp");
     A(d_keep, MR, "keep");
     A(d_unit_state, MR, "unit_state");
     A(d_hits, MR, "hits");
@@ -1049,7 +1046,6 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     pa.w = c->index->w;
     pa.prefix_length = prefix_length;
     pa.tile_windows = c->tile_windows;
-    pa.read_windows = c->d_read_windows;
     pa.read_tiles = c->d_read_tiles;
     pa.read_tile_first = c->d_read_tile_first;
     pa.unit_first_read = c->d_unit_first_read;
@@ -1177,7 +1173,8 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         da.set_capacity = 4 * c->rec_capacity + 64;
         da.n_units = n_units;
         da.status = c->d_status;
-        DCN_TRY(dcn_launch_distinct(da, c->d_caps, c->d_scan_tmp, st));
+        da.caps = c->d_caps;
+    DCN_TRY(dcn_launch_distinct(da, st));
         dcn_finish_args fa;
         fa.n_units = n_units;
         fa.unit_first_read = nullptr;
@@ -1262,8 +1259,7 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             pa.w = idx->w;
             pa.prefix_length = 0;
             pa.tile_windows = c->tile_windows;
-            pa.read_windows = c->d_read_windows;
-            pa.read_tiles = c->d_read_tiles;
+                    pa.read_tiles = c->d_read_tiles;
             pa.read_tile_first = c->d_read_tile_first;
             pa.unit_first_read = c->d_unit_first_read;
             pa.unit_tile_first = c->d_unit_tile_first;

@@ -95,6 +95,9 @@ struct dcn_status {
     unsigned long long rec_count[DCN_REC_SHARDS]; // hit records appended per shard (may exceed the segment size)
     uint32_t rec_overflow;                        // records dropped: a segment of the record buffer was too small
     uint32_t n_tiles;
+    uint32_t any_records;                         // some kernel appended a hit record: the distinct pass has work
+    uint32_t reserved;
+    unsigned long long set_cursor;                // distinct pass: slots handed out to the per-unit hash sets
     unsigned long long stats[DCN_N_STATS];
 };
 
@@ -154,10 +157,6 @@ int dcn_table_count_valid(const uint8_t *d_valid, uint64_t n, uint64_t *count, h
 int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity, uint64_t *n_out);
 int dcn_table_merge(dcn_index *dst, const dcn_index *src, const dcn_index *minus);
 
-// exclusive prefix sum of n u32 values into out[0..n] (out[n] = total); tmp holds ceil(n/1024)+1 words
-int dcn_launch_exclusive_scan(const uint32_t *d_in, uint32_t *d_out, uint32_t n, uint32_t *d_tmp,
-                              hipStream_t stream);
-uint32_t dcn_scan_tmp_words(uint32_t n);
 
 // required = max(abs, total==0 ? 0 : max(1, round_half_away(rel*total)))  (src/filter_common.rs:84-96)
 __host__ __device__ inline uint64_t dcn_required_hits(uint64_t abs_threshold, double rel_threshold,

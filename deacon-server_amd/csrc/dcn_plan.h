@@ -11,8 +11,7 @@ struct dcn_plan_args {
     uint32_t k, w;
     uint64_t prefix_length;
     uint32_t tile_windows;
-    uint32_t *read_windows;     // n_reads
-    uint32_t *read_tiles;       // n_reads: tiles of each read
+    uint32_t *read_tiles;       // n_reads: tiles of each read (may be null together with read_tile_first)
     uint32_t *read_tile_first;  // n_reads: first tile of each read (tile ranges of different reads never overlap)
     uint32_t *unit_first_read;  // n_units + 1 (only written when unit_id != null)
     uint32_t *unit_tile_first;  // n_units: first tile of the unit
@@ -29,7 +28,8 @@ struct dcn_distinct_args {
     const uint32_t *g_hitcnt;
     uint32_t *g_distinct;
     uint32_t *g_zero;
-    uint32_t *set_off; // n_units + 1
+    uint32_t *set_off; // n_units: first slot of a unit's region (only for units with records)
+    uint32_t *caps;    // n_units: region size (power of two), 0 = no records
     uint64_t *set_slots;
     uint64_t set_capacity;
     uint32_t n_units;
@@ -65,6 +65,6 @@ struct dcn_probe_hashes_args {
 };
 
 int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream);
-int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *d_scan_tmp, hipStream_t stream);
+int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream);
 int dcn_launch_finish(const dcn_finish_args &a, hipStream_t stream);
 int dcn_launch_probe_hashes(const dcn_probe_hashes_args &a, hipStream_t stream);

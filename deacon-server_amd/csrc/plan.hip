@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
         const uint32_t r = block_first + c * 256 + tid;
         if (r >= a.n_reads) continue;
         const uint32_t first = s_base + loc[c];
-        a.read_windows[r] = nwin[c];
-        a.read_tiles[r] = nt[c];
-        a.read_tile_first[r] = first;
+        if (a.read_tiles) { // only the minimizer dump reads these back
+            a.read_tiles[r] = nt[c];
+            a.read_tile_first[r] = first;
+        }
         uint32_t u = r;
         bool unit_head = true;
         if (a.unit_id) {
@@ -135,7 +136,12 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
 }
 
 // ---- exact distinct-hit count from (unit, hash) records ------------------------------------------------------
-__global__ __launch_bounds__(256) void distinct_cap_kernel(const uint32_t *g_hitcnt, uint32_t n_units, uint32_t *caps) {
+// (every kernel of the distinct pass returns at once when no hit record was appended in this batch)
+// A unit with hit records gets a power-of-two region of >= 2x its record count; regions are handed out from one
+// cursor in whatever order the units arrive (only units spanning waves have records, so the atomics are few).
+__global__ __launch_bounds__(256) void distinct_cap_kernel(const uint32_t *g_hitcnt, uint32_t n_units, uint32_t *caps,
+                                                          uint32_t *set_off, dcn_status *status) {
+    if (status->any_records == 0) return;
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_units) return;
     uint32_t hc = g_hitcnt[u];
@@ -143,20 +149,22 @@ __global__ __launch_bounds__(256) void distinct_cap_kernel(const uint32_t *g_hit
     if (hc) {
         cap = 2;
         while (cap < 2u * hc && cap < (1u << 31)) cap <<= 1;
+        set_off[u] = (uint32_t)atomicAdd(&status->set_cursor, (unsigned long long)cap);
     }
     caps[u] = cap;
 }
 
-__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, const uint32_t *set_off,
-                                                            uint32_t n_units, uint64_t capacity) {
-    uint64_t total = set_off[n_units];
+__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, const dcn_status *status) {
+    if (status->any_records == 0) return;
+    uint64_t total = status->set_cursor;
     if (total > capacity) total = capacity;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) set_slots[i] = 0;
 }
 
 __global__ __launch_bounds__(256) void distinct_insert_kernel(dcn_distinct_args a) {
-    uint64_t total_slots = a.set_off[a.n_units];
+    if (a.status->any_records == 0) return;
+    uint64_t total_slots = a.status->set_cursor;
     if (total_slots > a.set_capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) a.status->rec_overflow = 1;
         return;
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256) void distinct_insert_kernel(dcn_distinct_args 
                 if (h == 0) { // 0 marks an empty slot: a zero hash is tracked by a per-unit flag
                     fresh = atomicExch(&a.g_zero[u], 1u) == 0u;
                 } else {
-                    uint32_t cap = a.set_off[u + 1] - a.set_off[u];
+                    uint32_t cap = a.caps[u];
                     unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
                     uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
                     uint32_t slot = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x85EBCA6Bu) & (cap - 1);
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(256) void probe_hashes_kernel(dcn_probe_hashes_args
             else hi = mid - 1;
         }
         unsigned long long r = atomicAdd(&a.status->rec_count[shard], 1ull);
+        a.status->any_records = 1;
         if (r < seg) {
             a.rec_unit[shard * seg + r] = lo;
             a.rec_hash[shard * seg + r] = h;
@@ -313,13 +322,10 @@ int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream) {
     return DCN_OK;
 }
 
-int dcn_launch_distinct(const dcn_distinct_args &a, uint32_t *d_caps, uint32_t *d_scan_tmp, hipStream_t stream) {
+int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream) {
     hipLaunchKernelGGL(distinct_cap_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a.g_hitcnt,
-                       a.n_units, d_caps);
-    int rc = dcn_launch_exclusive_scan(d_caps, a.set_off, a.n_units, d_scan_tmp, stream);
-    if (rc != DCN_OK) return rc;
-    hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_off, a.n_units,
-                       a.set_capacity);
+                       a.n_units, a.caps, a.set_off, a.status);
+    hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_capacity, a.status);
     hipLaunchKernelGGL(distinct_insert_kernel, dim3(DCN_REC_SHARDS * 32), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;

@@ -360,7 +360,10 @@ __global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_
                         const uint32_t shard = blockIdx.x % DCN_REC_SHARDS;
                         const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
                         unsigned long long base = 0;
-                        if (lane == 0) base = atomicAdd(&a.status->rec_count[shard], (unsigned long long)nrec);
+                        if (lane == 0) {
+                            base = atomicAdd(&a.status->rec_count[shard], (unsigned long long)nrec);
+                            a.status->any_records = 1;
+                        }
                         base = __shfl(base, 0, 64);
                         const uint32_t rank = (uint32_t)__popcll(rb & lt);
                         const unsigned long long below = rb & lt;

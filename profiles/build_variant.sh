@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../deacon-server_amd/csrc"
 out=../lib/variants; mkdir -p $out ../build/var_$name
-for f in api.hip index_table.hip pack.hip prefix_scan.hip plan.hip scan.hip index_file.cpp; do
+for f in api.hip index_table.hip pack.hip plan.hip scan.hip index_file.cpp; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-result -x hip "$@" -c $f -o ../build/var_$name/${f%.*}.o &
 done
 wait

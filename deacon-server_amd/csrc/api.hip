@@ -413,9 +413,8 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     hipStream_t st = c->stream;
     const dcn_index *idx = c->index;
     // per-batch scratch: status header (not the counters), per-unit state
+    // (the per-unit state and scratch words are cleared by the plan kernel)
     DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
-    DCN_HIP(hipMemsetAsync(c->d_unit_state, 0, n_units, st));
-    DCN_HIP(hipMemsetAsync(c->d_unit_scratch, 0, (uint64_t)c->max_reads * 4 * sizeof(uint32_t), st));
 
     int prof_slot = -1;
     DCN_TRY(prof_begin(c, &prof_slot));
@@ -423,7 +422,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     DCN_TRY(dcn_launch_pack(d_bases, n_bases, packed, invmask, st));
     DCN_PROF_MARK(DCN_STAGE_PACK);
 
-    dcn_plan_args pa;
+    dcn_plan_args pa = {};
     pa.ascii = d_bases;
     pa.offsets = d_offsets;
     pa.unit_id = d_unit_id;
@@ -436,6 +435,9 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     pa.read_tiles = nullptr; // per-read tile ranges are only needed by the minimizer dump
     pa.read_tile_first = nullptr;
     pa.unit_first_read = c->d_unit_first_read;
+    pa.unit_state = c->d_unit_state;
+    pa.unit_scratch = c->d_unit_scratch;
+    pa.scratch_stride = c->max_reads;
     pa.unit_tile_first = c->d_unit_tile_first;
     pa.unit_tile_count = c->d_unit_tile_count;
     pa.tile_cursor = &c->d_status->n_tiles;
@@ -1036,7 +1038,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
     uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
     DCN_TRY(dcn_launch_pack(c->d_ascii, n_bases, packed, invmask, st));
-    dcn_plan_args pa;
+    dcn_plan_args pa = {};
     pa.ascii = c->d_ascii;
     pa.offsets = c->d_offsets;
     pa.unit_id = nullptr;
@@ -1249,7 +1251,7 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             DCN_HIP(hipMemsetAsync(c->d_dump_valid, 0, nb + 2, st));
             uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
             DCN_TRY(dcn_launch_pack(c->d_ascii, nb, packed, invmask, st, /*index_side=*/true));
-            dcn_plan_args pa;
+            dcn_plan_args pa = {};
             pa.ascii = c->d_ascii;
             pa.offsets = c->d_offsets;
             pa.unit_id = nullptr;

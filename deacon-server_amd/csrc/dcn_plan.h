@@ -16,6 +16,9 @@ struct dcn_plan_args {
     uint32_t *unit_first_read;  // n_units + 1 (only written when unit_id != null)
     uint32_t *unit_tile_first;  // n_units: first tile of the unit
     uint32_t *unit_tile_count;  // n_units: its tile count; 0xFFFFFFFF = tiles not contiguous (never resolved in-wave)
+    uint8_t *unit_state;        // n_units, cleared here (1 = resolved by the scan kernel)
+    uint32_t *unit_scratch;     // g_total | g_hitcnt | g_distinct | g_zero, scratch_stride entries each, cleared here
+    uint32_t scratch_stride;
     dcn_tile *tiles;
     uint32_t *tile_cursor;      // global tile counter (= &status->n_tiles, zeroed per batch)
     dcn_status *status;

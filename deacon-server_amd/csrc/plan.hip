@@ -119,6 +119,12 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
             }
             a.unit_tile_first[u] = first;
             a.unit_tile_count[u] = count;
+            // per-unit scratch of this batch starts from zero (saves two memset launches per batch)
+            if (a.unit_state) { // null for the minimizer dump / index build, which keep no per-unit state
+                a.unit_state[u] = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) a.unit_scratch[(uint64_t)q * a.scratch_stride + u] = 0;
+            }
         }
         const uint64_t off = a.offsets[r];
         for (uint32_t j = 0; j < min(nt[c], OWN); ++j) write_tile(a, first, j, off, nwin[c], u);

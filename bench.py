@@ -425,6 +425,10 @@ def main():
                 "bound": "hbm", "kernel": "scan_kernel<15> (scan+hash+probe+distinct)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                # measured HBM traffic (PMC, profiles/r01_traffic.json) over the live launch time: the rate the probe
+                # kernel actually pulls from HBM, against the same 8 TB/s
+                "traffic_rate_GBps": (traffic / (scan_ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_frac_of_peak": (traffic / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": scan_ms,
                 "minimizers_per_launch": n_minimizers // C,
                 # second ceiling, reported beside the contract's: every minimizer is one scattered 16-byte

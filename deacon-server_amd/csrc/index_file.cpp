@@ -9,7 +9,10 @@
 // to the device table builder, which merges duplicates.
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "dcn_internal.h"
@@ -100,44 +103,91 @@ int dcn_read_index_file(const char *path, uint8_t *k, uint8_t *w, std::vector<ui
     return rc;
 }
 
-// write_minimizers (src/index.rs:130-164): header, count, then every hash as a bincode varint
+// write_minimizers (src/index.rs:130-164): header, count, then every hash as a bincode varint.
+// Blocks of 8 Mi hashes are encoded by a few threads (sizes first, then each thread writes its part of the block at
+// its offset) while the previous block is being written out.
+namespace {
+
+inline size_t varint_size(uint64_t v) { return v < 251 ? 1 : v <= 0xFFFFull ? 3 : v <= 0xFFFFFFFFull ? 5 : 9; }
+
+inline uint8_t *put_varint(uint8_t *p, uint64_t v) {
+    if (v < 251) {
+        *p++ = (uint8_t)v;
+        return p;
+    }
+    size_t nb;
+    if (v <= 0xFFFFull) {
+        *p++ = 0xFB;
+        nb = 2;
+    } else if (v <= 0xFFFFFFFFull) {
+        *p++ = 0xFC;
+        nb = 4;
+    } else {
+        *p++ = 0xFD;
+        nb = 8;
+    }
+    memcpy(p, &v, nb); // little-endian host
+    return p + nb;
+}
+
+// encodes keys[0..n) into out (resized to the exact byte count) with `threads` workers
+void encode_block(const uint64_t *keys, size_t n, unsigned threads, std::vector<uint8_t> &out) {
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 65536 + 1));
+    std::vector<size_t> part(threads + 1, 0);
+    auto range = [&](unsigned t, size_t &lo, size_t &hi) {
+        lo = n * t / threads;
+        hi = n * (t + 1) / threads;
+    };
+    auto run = [&](auto &&fn) {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; ++t) pool.emplace_back(fn, t);
+        fn(0u);
+        for (auto &th : pool) th.join();
+    };
+    run([&](unsigned t) {
+        size_t lo, hi, bytes = 0;
+        range(t, lo, hi);
+        for (size_t i = lo; i < hi; ++i) bytes += varint_size(keys[i]);
+        part[t + 1] = bytes;
+    });
+    for (unsigned t = 0; t < threads; ++t) part[t + 1] += part[t];
+    out.resize(part[threads]);
+    run([&](unsigned t) {
+        size_t lo, hi;
+        range(t, lo, hi);
+        uint8_t *p = out.data() + part[t];
+        for (size_t i = lo; i < hi; ++i) p = put_varint(p, keys[i]);
+    });
+}
+
+} // namespace
+
 int dcn_write_index_file(const char *path, uint8_t k, uint8_t w, const uint64_t *keys, uint64_t n) {
     FILE *f = fopen(path, "wb");
     if (!f) return dcn_fail(DCN_ERR_IO, std::string("Failed to create output file ") + path);
-    std::vector<uint8_t> buf;
-    buf.reserve(1 << 22);
-    auto put_varint = [&](uint64_t v) {
-        if (v < 251) {
-            buf.push_back((uint8_t)v);
-            return;
-        }
-        size_t nb;
-        if (v <= 0xFFFFull) {
-            buf.push_back(0xFB);
-            nb = 2;
-        } else if (v <= 0xFFFFFFFFull) {
-            buf.push_back(0xFC);
-            nb = 4;
-        } else {
-            buf.push_back(0xFD);
-            nb = 8;
-        }
-        for (size_t i = 0; i < nb; ++i) buf.push_back((uint8_t)(v >> (8 * i)));
-    };
-    buf.push_back(2);
-    buf.push_back(k);
-    buf.push_back(w);
-    put_varint(n);
-    int rc = DCN_OK;
-    for (uint64_t i = 0; i < n && rc == DCN_OK; ++i) {
-        put_varint(keys[i]);
-        if (buf.size() >= (1u << 22) - 16) {
-            if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) rc = dcn_fail(DCN_ERR_IO, "short write");
-            buf.clear();
-        }
+    setvbuf(f, nullptr, _IONBF, 0); // blocks are tens of megabytes: no second copy through stdio
+    uint8_t head[3 + 9] = {2, k, w};
+    size_t head_len = (size_t)(put_varint(head + 3, n) - head);
+    int rc = fwrite(head, 1, head_len, f) == head_len ? DCN_OK : dcn_fail(DCN_ERR_IO, "short write");
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned threads = std::min(8u, hw ? hw : 1u);
+    if (const char *e = getenv("DCN_HOST_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    const uint64_t BLOCK = 8ull << 20;
+    std::vector<uint8_t> buf[2];
+    std::thread writer;
+    bool write_failed = false;
+    int which = 0;
+    for (uint64_t off = 0; off < n && rc == DCN_OK; off += BLOCK, which ^= 1) {
+        encode_block(keys + off, (size_t)std::min<uint64_t>(BLOCK, n - off), threads, buf[which]);
+        if (writer.joinable()) writer.join(); // the other buffer has been written: it is free for the next block
+        if (write_failed) break;
+        std::vector<uint8_t> *b = &buf[which];
+        writer = std::thread([f, b, &write_failed] {
+            if (fwrite(b->data(), 1, b->size(), f) != b->size()) write_failed = true;
+        });
     }
-    if (rc == DCN_OK && !buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size())
-        rc = dcn_fail(DCN_ERR_IO, "short write");
+    if (writer.joinable()) writer.join();
+    if (write_failed && rc == DCN_OK) rc = dcn_fail(DCN_ERR_IO, "short write");
     if (fclose(f) != 0 && rc == DCN_OK) rc = dcn_fail(DCN_ERR_IO, "close failed");
     return rc;
 }

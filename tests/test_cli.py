@@ -366,3 +366,34 @@ def test_batches_cut_into_several_calls(tmp_path, oracle, paired, monkeypatch):
     lines = out.split("\n")
     assert lines[1::4][:len(want)] == want and len([l for l in lines[1::4] if l]) == len(want)
     assert [l for l in lines[0::4] if l] == [f"@{i + 1}" for i in range(len(want))]  # --rename numbers across calls
+
+
+@gpu
+def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
+    """The mmap parser cuts the file at record boundaries it has to find from the middle of nowhere: qualities that
+    start with '@' or '+', ids containing '+', Windows line ends and a missing final newline must not move a cut."""
+    rng = np.random.default_rng(58)
+    genome = random_reads(rng, 1, 30_000, 30_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    oidx = oracle.Index.build([genome])
+    reads, lines = [], []
+    for i in range(40_000):
+        ln = int(rng.integers(40, 120))
+        s = int(rng.integers(0, len(genome) - ln))
+        r = mutate(rng, genome[s:s + ln], 0.02) if i % 3 else random_reads(rng, 1, ln, ln)[0]
+        reads.append(r)
+        q = bytearray(rng.integers(33, 74, ln, dtype=np.uint8).tobytes())
+        q[0] = ord("@") if i % 2 else ord("+")
+        if ln > 1 and i % 5 == 0:
+            q[1] = ord("@")
+        lines.append(b"@r%d +x @y\n%s\n+\n%s\n" % (i, r, bytes(q)))
+    data = b"".join(lines)
+    monkeypatch.setenv("DCN_CLI_CHUNK_MB", "1")
+    b, o = oracle.concat_reads(reads)
+    keep, _, _ = oracle.filter_batch(oidx, b, o)
+    want = [f"r{i} +x @y" for i in range(len(reads)) if keep[i]]
+    for name, payload in (("unix.fq", data), ("nofinalnl.fq", data[:-1]), ("dos.fq", data.replace(b"\n", b"\r\n"))):
+        (tmp_path / name).write_bytes(payload)
+        out = run("filter", idx, tmp_path / name, "-t", 6).stdout
+        got = [l[1:].rstrip(b"\r").decode() for l in out.split(b"\n")[0::4] if l]
+        assert got == want, name

@@ -307,6 +307,24 @@ def test_filter_long_reads(oracle, dcn, genome, index_pair):
     assert hits.max() > 300
 
 
+def test_one_very_long_read(oracle, dcn, genome, index_pair):
+    """A chromosome-sized record among short reads: tens of thousands of tiles of one unit (planned by the whole
+    workgroup), read positions far beyond 2^24, a relative threshold that asks for thousands of distinct hits."""
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(42)
+    big = bytearray(random_reads(rng, 1, 24_000_000, 24_000_000)[0])
+    for s in range(0, len(big) - len(genome), 3_000_000):  # copies of the indexed genome inside it -> real hits, repeated
+        big[s:s + len(genome)] = genome
+    big[5_000_000:5_000_200] = b"N" * 200
+    reads = sample_reads(rng, genome, 200, 100, 200) + [bytes(big)] + sample_reads(rng, genome, 200, 100, 200)
+    for rel in (0.0, 0.002, 0.5):
+        proc = dcn.FilterProcessor(gidx, abs_threshold=2, rel_threshold=rel, max_batch_bases=len(big) + (1 << 20),
+                                   max_batch_reads=1 << 10)
+        keep, hits, total = check_batch(oracle, proc, oidx, reads)
+        assert total[200] > 2_000_000 and hits[200] > 10_000
+    assert keep[200] == 0  # -r 0.5: half of its minimizers would have to hit
+
+
 def test_repeats_inside_long_reads_are_counted_once(oracle, dcn, genome, index_pair):
     oidx, gidx = index_pair
     seg = genome[1000:3000]

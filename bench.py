@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=4_000_000, help="reads per batch per GPU (150 bp each)")
     ap.add_argument("--index-keys", type=int, default=PANHUMAN_KEYS)
-    ap.add_argument("--host-genome", type=int, default=16_000_000, help="bases of the synthetic host genome")
+    ap.add_argument("--host-genome", type=int, default=64_000_000,
+                    help="bases of the synthetic host genome (SURVEY.md 8d config 2: 64 Mbp, ~8 M of the index keys)")
     ap.add_argument("--contexts", type=int, default=1,
                     help="pipeline contexts per GPU: the step's batch is split into this many sub-batches, each on its "
                          "own context/stream, so pack+plan of one overlap the scan of another")
@@ -396,7 +397,7 @@ def main():
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             wlk = tr["workload"]
             if (args.workload == wlk["workload"] and n_reads == wlk["reads_per_batch"] and C == 1
-                    and int(index.n_keys) == wlk["index_keys"]):
+                    and int(index.n_keys) == wlk["index_keys"] and args.host_genome == wlk.get("host_genome_bases")):
                 traffic = tr["scan_kernel"]["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -418,7 +419,7 @@ def main():
                              "paired": "configs[3]: paired 2x150 bp --deplete vs panhuman-1-sized index, inputs resident in HBM as ASCII",
                              "long": "configs[2]: ONT-style lognormal reads (mean 10 kbp) vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII"}[args.workload],
                 "index_keys": int(index.n_keys), "reads_per_batch_per_gpu": n_reads, "bases_per_batch_per_gpu": n_bases,
-                "k": K, "w": W, "host_fraction": 0.5, "parallelism": f"reads sharded x{world}, index replicated",
+                "k": K, "w": W, "host_fraction": 0.5, "host_genome_bases": args.host_genome, "parallelism": f"reads sharded x{world}, index replicated",
                 "contexts_per_gpu": C,
             },
             "roofline": {

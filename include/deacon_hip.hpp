@@ -166,7 +166,26 @@ class FilterProcessor {
         for (std::size_t u = 0; u < n_units; ++u) out[u] = Decision(keep_[u] != 0, hits_[u], total_[u]);
         return out;
     }
+    // Decisions only: what the filter loop consumes outside --debug (local_filter.rs:350-371).  No hit counts are
+    // returned, so the kernels stop probing a unit once its decision is fixed.  One bool per unit, in input order.
+    std::vector<bool> keep_batch(const std::vector<std::string_view> &reads, bool paired) {
+        bases_.clear();
+        offsets_.assign(1, 0);
+        unit_id_.clear();
+        for (std::size_t i = 0; i < reads.size(); ++i) {
+            bases_.insert(bases_.end(), reads[i].begin(), reads[i].end());
+            offsets_.push_back(bases_.size());
+            if (paired) unit_id_.push_back(static_cast<uint32_t>(i / 2));
+        }
+        std::size_t n_units = paired ? (reads.size() + 1) / 2 : reads.size();
+        keep_.assign(n_units, 0);
+        dcn_params p = params();
+        check(dcn_filter_batch(ctx_, bases_.data(), offsets_.data(), paired ? unit_id_.data() : nullptr,
+                               static_cast<uint32_t>(reads.size()), &p, keep_.data(), nullptr, nullptr));
+        return std::vector<bool>(keep_.begin(), keep_.end());
+    }
     // Zero-copy form of the batch seam: concatenated bases + offsets (+ optional unit ids), outputs per unit.
+    // hits and total may both be null (decisions only).
     void filter_batch(const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id, uint32_t n_reads,
                       uint8_t *keep, uint32_t *hits, uint32_t *total) {
         dcn_params p = params();

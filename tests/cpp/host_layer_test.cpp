@@ -47,6 +47,12 @@ int main(int argc, char **argv) {
         auto res = proc.filter_batch(views, paired != 0);
         for (auto &[keep, hits, total] : res) std::printf("unit %d %zu %zu\n", keep ? 1 : 0, hits, total);
         auto st = proc.stats();
+        {   // decisions only: same answers; its counters are not part of the "stats" line printed below
+            auto only = proc.keep_batch(views, paired != 0);
+            std::printf("keeponly");
+            for (bool b : only) std::printf(" %d", b ? 1 : 0);
+            std::printf("\n");
+        }
         std::printf("stats %llu %llu %llu %llu %llu %llu\n", (unsigned long long)st.total_seqs,
                     (unsigned long long)st.filtered_seqs, (unsigned long long)st.total_bp,
                     (unsigned long long)st.output_bp, (unsigned long long)st.filtered_bp,

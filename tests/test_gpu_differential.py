@@ -1,6 +1,8 @@
 """Randomized differential test: GPU (through the C ABI) vs the oracle over random parameters and inputs --
 k, w, thresholds, prefix lengths, unit groupings, alphabets (N runs, IUPAC, lower case, newlines), read-length
 mixes that cross every tile / flush / ring boundary.  Seeds are fixed; every case prints its parameters on failure."""
+import os
+
 import numpy as np
 import pytest
 
@@ -55,7 +57,7 @@ def random_case(rng, genome):
     return k, w, reads, uid, params
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DCN_FUZZ_SEEDS", "12"))))  # more seeds for a soak run
 def test_differential(oracle, dcn, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     genome = random_reads(rng, 1, 60_000, 60_000)[0]

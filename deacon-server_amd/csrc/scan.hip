@@ -74,6 +74,9 @@ struct WaveShared {
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
 #endif
+#ifndef DCN_MIN_WAVES_FAST
+#define DCN_MIN_WAVES_FAST 4 // decisions-only instantiation
+#endif
 
 template <bool B>
 struct BoolTag {
@@ -91,7 +94,7 @@ struct IntTag {
 // FAST: the decisions-only instantiation (a.early_out_max_items != 0), kept apart so that the counting kernel's
 // register allocation does not carry the early-out path
 template <int W, bool K128, bool DUMP, bool FAST>
-__global__ __launch_bounds__(DCN_WAVE, DCN_MIN_WAVES) void scan_kernel(dcn_scan_args a) {
+__global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES) void scan_kernel(dcn_scan_args a) {
     __shared__ WaveShared sh;
     extern __shared__ uint2 dyn_ring[]; // only for W == 0: [w][64] (lkey, rkey)
 

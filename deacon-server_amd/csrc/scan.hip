@@ -74,6 +74,9 @@ struct WaveShared {
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
 #endif
+#ifndef DCN_FAST_EXTRA_ROUNDS
+#define DCN_FAST_EXTRA_ROUNDS 4 // own-list rounds beyond abs_threshold before the undecided rest is flattened
+#endif
 #ifndef DCN_MIN_WAVES_FAST
 #define DCN_MIN_WAVES_FAST 4 // decisions-only instantiation
 #endif
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             };
             // rounds 0 .. R1-1: lane = its own list.  Reads from the indexed genome are decided here.
             const uint32_t maxc = wave_max_u32(cnt_eff);
-            const uint32_t R1 = min(need + 2u, maxc);
+            const uint32_t R1 = min(need + (uint32_t)DCN_FAST_EXTRA_ROUNDS, maxc);
             for (uint32_t j = 0; j < R1; ++j) {
                 const bool actv = j < cnt_eff && nh < need;
                 if (!__any(actv)) break;

@@ -81,6 +81,14 @@ _SIGNATURES = {
     "dcn_ctx_create": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
     "dcn_ctx_destroy": (None, [_vp]),
     "dcn_filter_batch": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp]),
+    "dcn_filter_batch_submit": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp, _u64p]),
+    "dcn_filter_batch_wait": (C.c_int, [_vp, C.c_uint64]),
+    "dcn_filter_batch_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp]),
+    "dcn_filter_batch_packed_submit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp,
+                                                 _u64p]),
+    "dcn_pack_ascii": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
+    "dcn_stats_allreduce": (C.c_int, [C.POINTER(_vp), C.c_int, _u64p]),
+    "dcn_index_clone": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "dcn_filter_batch_device": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, C.c_uint32,
                                           C.POINTER(Params), _vp, _vp, _vp]),
     "dcn_ctx_synchronize": (C.c_int, [_vp]),

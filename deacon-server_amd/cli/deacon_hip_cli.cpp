@@ -111,14 +111,17 @@ class Output {
             die("write error");
         }
     }
+    // the last flush is where a full disk or a closed pipe shows: a failure here must not end in "Retained ..."
     void close() {
-        if (gz_) gzclose(gz_);
+        gzFile gz = gz_;
+        FILE *f = f_;
         gz_ = nullptr;
-        if (f_) {
-            std::fflush(f_);
-            if (own_) std::fclose(f_);
-        }
         f_ = nullptr;
+        if (gz && gzclose(gz) != Z_OK) die("write error");
+        if (f) {
+            if (std::fflush(f) != 0) die("write error");
+            if (own_ && std::fclose(f) != 0) die("write error");
+        }
     }
 
   private:
@@ -863,7 +866,7 @@ int run_filter(const FilterArgs &a) {
                      prop(filtered_seqs, total_seqs), (unsigned long long)total_bp, (unsigned long long)output_bp,
                      prop(output_bp, total_bp), (unsigned long long)filtered_bp, prop(filtered_bp, total_bp), secs,
                      (unsigned long long)(total_seqs / secs), (unsigned long long)(total_bp / secs));
-        std::fclose(f);
+        if (std::ferror(f) || std::fclose(f) != 0) die("Failed to write summary: " + a.summary);
         if (!quiet) std::fprintf(stderr, "Summary saved to \"%s\"\n", a.summary.c_str());
     }
     // Everything is written and closed.  Tearing the pipeline down in order (unmapping gigabytes of input, freeing

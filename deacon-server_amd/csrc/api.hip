@@ -10,10 +10,12 @@
 #include "dcn_plan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -56,6 +58,12 @@ extern "C" int dcn_device_count(int *count) {
 // index
 // ----------------------------------------------------------------------------------------------------
 int dcn_read_index_file(const char *path, uint8_t *k, uint8_t *w, std::vector<uint64_t> *keys); // index_file.cpp
+
+#define DCN_TRY_EARLY(expr)             \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != DCN_OK) return _rc; \
+    } while (0)
 
 static int check_kw(uint8_t k, uint8_t w) {
     if (k < 1 || k > 56) return dcn_fail(DCN_ERR_ARG, "k must be in 1..=56 (src/filter_common.rs:269-272)");
@@ -240,6 +248,43 @@ extern "C" int dcn_index_contains_device(const dcn_index *index, const uint64_t 
     return dcn_table_contains_device(index, d_keys, n, d_out, (hipStream_t)stream);
 }
 
+extern "C" int dcn_index_clone(const dcn_index *index, int device, dcn_index **out) {
+    if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (!index) return dcn_fail(DCN_ERR_ARG, "index is NULL");
+    int ndev = 0;
+    DCN_TRY_EARLY(dcn_device_count(&ndev));
+    if (device < 0 || device >= ndev) return dcn_fail(DCN_ERR_ARG, "no such HIP device");
+    dcn_index *idx = new (std::nothrow) dcn_index(*index);
+    if (!idx) return dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
+    idx->device = device;
+    idx->d_slots = nullptr;
+    const uint64_t bytes = idx->n_groups * DCN_GROUP_SLOTS * sizeof(uint64_t);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&idx->d_slots, std::max<uint64_t>(bytes, 16));
+    if (e == hipSuccess && bytes) {
+        if (device == index->device) {
+            e = hipMemcpy(idx->d_slots, index->d_slots, bytes, hipMemcpyDeviceToDevice);
+        } else {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, device, index->device);
+            if (can) {
+                hipError_t pe = hipDeviceEnablePeerAccess(index->device, 0);
+                if (pe != hipSuccess) (void)hipGetLastError(); // already enabled
+            }
+            e = hipMemcpyPeer(idx->d_slots, device, index->d_slots, index->device, bytes);
+        }
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (idx->d_slots) hipFree(idx->d_slots);
+        delete idx;
+        return dcn_fail(e == hipErrorOutOfMemory ? DCN_ERR_NOMEM : DCN_ERR_HIP, std::string("index clone: ") + hipGetErrorString(e));
+    }
+    *out = idx;
+    return DCN_OK;
+}
+
 extern "C" void dcn_index_destroy(dcn_index *index) {
     if (!index) return;
     hipSetDevice(index->device);
@@ -250,16 +295,58 @@ extern "C" void dcn_index_destroy(dcn_index *index) {
 // ----------------------------------------------------------------------------------------------------
 // context
 // ----------------------------------------------------------------------------------------------------
+// One pipeline step of a host batch: reads [r0, r1) = units [u0, u1) = bases [b0, b1) of the batch stream.
+struct dcn_chunk {
+    uint32_t r0 = 0, r1 = 0, u0 = 0, u1 = 0;
+    uint64_t b0 = 0, b1 = 0;
+};
+
+// One host batch in flight (dcn_filter_batch_submit .. dcn_filter_batch_wait).  Everything a later batch's copies
+// could overwrite while this batch's kernels still read it is per slot; the compute scratch (tiles, per-unit state,
+// hit records) is shared, because all kernels of a context run on one stream.  Slot 0 uses the context's own
+// buffers, slot 1 is allocated when a second batch is first submitted while slot 0 is busy.
+struct dcn_slot {
+    bool allocated = false, busy = false, owns_buffers = false;
+    uint64_t ticket = 0;
+    // device inputs / outputs
+    uint8_t *d_ascii = nullptr;
+    uint32_t *d_packed = nullptr, *d_invmask = nullptr;
+    uint64_t *d_offsets = nullptr;
+    uint32_t *d_unit_id = nullptr;
+    uint8_t *d_keep = nullptr;
+    uint32_t *d_hits = nullptr, *d_total = nullptr;
+    dcn_batch_report *d_report = nullptr;
+    // page-locked result staging (used when the caller's output arrays are pageable)
+    uint8_t *h_keep = nullptr;
+    uint32_t *h_hits = nullptr, *h_total = nullptr;
+    dcn_batch_report *h_report = nullptr;
+    hipEvent_t done = nullptr;
+    // the submitted batch, kept for result delivery and for the re-run after a record overflow
+    dcn_params params = {};
+    bool device_pack = false; // ASCII crossed the link: the pack kernel runs, read ends are probed for a newline
+    bool has_units = false, counts = false;
+    uint32_t n_reads = 0, n_units = 0;
+    uint64_t n_bases = 0;
+    uint8_t *u_keep = nullptr;
+    uint32_t *u_hits = nullptr, *u_total = nullptr;
+    bool keep_direct = false, hits_direct = false, total_direct = false; // caller's arrays are page-locked: copied into directly
+    std::vector<dcn_chunk> chunks;
+};
+
 struct dcn_ctx {
     const dcn_index *index = nullptr;
     int device = 0;
-    hipStream_t stream = nullptr, copy_stream = nullptr;
-    hipEvent_t copy_done = nullptr, stage_free[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr, copy_stream = nullptr, d2h_stream = nullptr;
+    static constexpr int N_STAGE = 3, N_EV = 8, N_SLOTS = 2;
+    hipEvent_t copy_done = nullptr, stage_free[N_STAGE] = {};
+    hipEvent_t ev_h2d[N_EV] = {}, ev_comp[N_EV] = {};
+    int ev_next = 0, stage_next = 0;
     uint64_t max_bases = 0;
     uint32_t max_reads = 0;
     uint32_t tile_windows = 512;
     uint32_t max_tiles = 0;
-    // device inputs (host API staging targets)
+    uint64_t chunk_bases = 0; // pipeline granularity of the host API (DCN_CHUNK_BASES)
+    // device inputs (host API staging targets of slot 0; also used by the minimizer dump and the index build)
     uint8_t *d_ascii = nullptr;
     uint64_t *d_offsets = nullptr;
     uint32_t *d_unit_id = nullptr;
@@ -280,18 +367,22 @@ struct dcn_ctx {
     uint64_t *d_rec_hash = nullptr;
     uint64_t *d_set_slots = nullptr;
     dcn_status *d_status = nullptr;
-    // pinned host staging
-    uint8_t *h_stage[2] = {nullptr, nullptr};
+    dcn_batch_report *d_report = nullptr; // device-pointer API: counters + sticky overflow since the last synchronize
+    dcn_batch_report *h_report = nullptr; // page-locked
+    uint64_t host_stats[DCN_N_STATS] = {}; // counters of completed host batches
+    // pinned host staging (pageable inputs)
+    uint8_t *h_stage[N_STAGE] = {};
     uint64_t stage_bytes = 0;
-    dcn_status *h_status = nullptr;
+    dcn_slot slots[N_SLOTS];
+    uint64_t next_ticket = 1;
     // dump mode buffers (lazy)
     uint64_t *d_dump_hash = nullptr;
     uint32_t *d_dump_pos = nullptr, *d_dump_count = nullptr;
     uint8_t *d_dump_valid = nullptr;
-    // deferred state of the last enqueued batch
+    // deferred state of the last enqueued device-API batch
     bool batch_pending = false;
     // optional per-stage timing: a ring of event sets, one per batch in flight
-    static constexpr int PROF_RING = 32;
+    static constexpr int PROF_RING = 64;
     bool profiling = false;
     hipEvent_t prof_ev[PROF_RING][DCN_N_STAGES + 1] = {};
     bool prof_used[PROF_RING] = {};
@@ -338,29 +429,50 @@ int alloc_records(dcn_ctx *c, uint64_t n_records) {
     return DCN_OK;
 }
 
+void free_slot_buffers(dcn_slot &sl) {
+    if (sl.owns_buffers) {
+        void *dev[] = {sl.d_ascii, sl.d_packed, sl.d_invmask, sl.d_offsets, sl.d_unit_id, sl.d_keep, sl.d_hits, sl.d_total};
+        for (void *p : dev)
+            if (p) hipFree(p);
+    }
+    if (sl.d_report) hipFree(sl.d_report);
+    void *host[] = {sl.h_keep, sl.h_hits, sl.h_total, sl.h_report};
+    for (void *p : host)
+        if (p) hipHostFree(p);
+    if (sl.done) hipEventDestroy(sl.done);
+    sl = dcn_slot();
+}
+
 void free_ctx(dcn_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+    if (c->d2h_stream) hipStreamSynchronize(c->d2h_stream);
+    for (auto &sl : c->slots) free_slot_buffers(sl);
     void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask,
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
                    c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
-                   c->d_set_off, c->d_rec_unit, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_dump_hash,
+                   c->d_set_off, c->d_rec_unit, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
     for (void *p : dev)
         if (p) hipFree(p);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < dcn_ctx::N_STAGE; ++i) {
         if (c->h_stage[i]) hipHostFree(c->h_stage[i]);
         if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
     }
-    if (c->h_status) hipHostFree(c->h_status);
+    for (int i = 0; i < dcn_ctx::N_EV; ++i) {
+        if (c->ev_h2d[i]) hipEventDestroy(c->ev_h2d[i]);
+        if (c->ev_comp[i]) hipEventDestroy(c->ev_comp[i]);
+    }
+    if (c->h_report) hipHostFree(c->h_report);
     for (int i = 0; i < dcn_ctx::PROF_RING; ++i)
         for (int j = 0; j <= DCN_N_STAGES; ++j)
             if (c->prof_ev[i][j]) hipEventDestroy(c->prof_ev[i][j]);
     if (c->copy_done) hipEventDestroy(c->copy_done);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->d2h_stream) hipStreamDestroy(c->d2h_stream);
     delete c;
 }
 
@@ -406,26 +518,41 @@ int check_params(const dcn_params *p) {
     return DCN_OK;
 }
 
-// enqueue the whole device pipeline for one batch whose ASCII / offsets / unit ids are in device memory
-int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets, const uint32_t *d_unit_id,
-                  uint32_t n_reads, uint64_t n_bases, uint32_t n_units, const dcn_params *params, uint8_t *d_keep,
-                  uint32_t *d_hits, uint32_t *d_total) {
+// What one run of the device pipeline works on: a whole batch of the device-pointer API, or one chunk of a host
+// batch.  Base offsets in d_offsets are positions in the batch stream (d_ascii / d_packed are the stream's
+// origin); read and unit indices are local to the view (arrays already point at the view's first entry).
+struct BatchView {
+    const uint8_t *d_ascii = nullptr;  // null: the stream arrived packed (no pack kernel, no newline probe)
+    uint32_t *d_packed = nullptr, *d_invmask = nullptr; // allocation starts (DCN_FRONT_PAD words in front of base 0)
+    const uint64_t *d_offsets = nullptr;
+    const uint32_t *d_unit_id = nullptr;
+    uint32_t unit_base = 0;
+    uint32_t n_reads = 0, n_units = 0;
+    uint64_t b0 = 0, b1 = 0; // bases of the stream this view covers
+    uint8_t *d_keep = nullptr;
+    uint32_t *d_hits = nullptr, *d_total = nullptr;
+    dcn_batch_report *d_report = nullptr;
+};
+
+// enqueue the whole device pipeline for one view on the context's compute stream
+int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     hipStream_t st = c->stream;
     const dcn_index *idx = c->index;
-    // per-batch scratch: status header (not the counters), per-unit state
-    // (the per-unit state and scratch words are cleared by the plan kernel)
-    DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
+    // per-run scratch: the status words (the per-unit state and scratch words are cleared by the plan kernel)
+    DCN_HIP(hipMemsetAsync(c->d_status, 0, sizeof(dcn_status), st));
 
     int prof_slot = -1;
     DCN_TRY(prof_begin(c, &prof_slot));
-    uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
-    DCN_TRY(dcn_launch_pack(d_bases, n_bases, packed, invmask, st));
+    uint32_t *packed = v.d_packed + DCN_FRONT_PAD, *invmask = v.d_invmask + DCN_FRONT_PAD;
+    if (v.d_ascii) DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, c->d_status, st));
     DCN_PROF_MARK(DCN_STAGE_PACK);
 
+    const uint32_t n_reads = v.n_reads, n_units = v.n_units;
     dcn_plan_args pa = {};
-    pa.ascii = d_bases;
-    pa.offsets = d_offsets;
-    pa.unit_id = d_unit_id;
+    pa.ascii = v.d_ascii;
+    pa.offsets = v.d_offsets;
+    pa.unit_id = v.d_unit_id;
+    pa.unit_base = v.unit_base;
     pa.n_reads = n_reads;
     pa.n_units = n_units;
     pa.k = idx->k;
@@ -465,7 +592,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     // decisions only: largest list length whose required hits still equal abs_threshold (dcn_required_hits is
     // monotone in the total); the scan kernel's lanes then stop at abs_threshold distinct hits (scan.hip)
     sa.early_out_max_items = 0;
-    if (!d_hits && !d_total && params->abs_threshold >= 1 && params->abs_threshold <= 4 && !getenv("DCN_NO_EARLY_OUT")) {
+    if (!v.d_hits && !v.d_total && params->abs_threshold >= 1 && params->abs_threshold <= 4 && !getenv("DCN_NO_EARLY_OUT")) {
         uint32_t lo = 0, hi = 65535; // required(lo) == abs always holds for lo = 0
         while (lo < hi) {
             uint32_t mid = (lo + hi + 1) / 2;
@@ -475,9 +602,9 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
         sa.early_out_max_items = lo;
         sa.early_out_pairs = getenv("DCN_NO_EARLY_OUT_PAIRS") ? 0u : 1u;
     }
-    sa.keep = d_keep;
-    sa.hits = d_hits;
-    sa.total = d_total;
+    sa.keep = v.d_keep;
+    sa.hits = v.d_hits;
+    sa.total = v.d_total;
     sa.unit_state = c->d_unit_state;
     sa.g_total = g_total;
     sa.g_hitcnt = g_hitcnt;
@@ -485,7 +612,7 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
     sa.rec_hash = c->d_rec_hash;
     sa.rec_capacity = c->rec_capacity;
     sa.status = c->d_status;
-    uint64_t tile_bound = (uint64_t)n_reads + n_bases / c->tile_windows + 1;
+    uint64_t tile_bound = (uint64_t)n_reads + (v.b1 - v.b0) / c->tile_windows + 1;
     if (tile_bound > c->max_tiles) tile_bound = c->max_tiles;
     DCN_TRY(dcn_launch_scan(sa, (uint32_t)tile_bound, false, st));
     DCN_PROF_MARK(DCN_STAGE_SCAN);
@@ -508,77 +635,86 @@ int enqueue_batch(dcn_ctx *c, const uint8_t *d_bases, const uint64_t *d_offsets,
 
     dcn_finish_args fa;
     fa.n_units = n_units;
-    fa.unit_first_read = d_unit_id ? c->d_unit_first_read : nullptr;
-    fa.offsets = d_offsets;
+    fa.unit_first_read = v.d_unit_id ? c->d_unit_first_read : nullptr;
+    fa.offsets = v.d_offsets;
     fa.unit_state = c->d_unit_state;
     fa.g_total = g_total;
     fa.g_distinct = g_distinct;
     fa.abs_threshold = params->abs_threshold;
     fa.rel_threshold = params->rel_threshold;
     fa.deplete = params->deplete;
-    fa.keep = d_keep;
-    fa.hits = d_hits;
-    fa.total = d_total;
-    fa.status_stats = c->d_status->stats;
+    fa.keep = v.d_keep;
+    fa.hits = v.d_hits;
+    fa.total = v.d_total;
+    fa.report = v.d_report;
     fa.status = c->d_status;
     DCN_TRY(dcn_launch_finish(fa, st));
     DCN_PROF_MARK(DCN_STAGE_FINISH);
     if (prof_slot >= 0) c->prof_used[prof_slot] = true;
-    c->batch_pending = true;
     return DCN_OK;
 }
 
-// wait for the compute stream and surface deferred pipeline errors
+int overflow_error(const dcn_ctx *c, uint64_t need) {
+    return dcn_fail(DCN_ERR_CAPACITY, "hit-record scratch overflow: need " + std::to_string(need) +
+                                          " records, have " + std::to_string(c->rec_capacity) +
+                                          " (dcn_ctx_reserve_records)");
+}
+
+// Wait for the compute stream and surface deferred errors of the device-pointer API.  The overflow word is
+// sticky across batches (the per-run status words are not): an overflow in ANY batch enqueued since the last
+// synchronize is reported here, however many smaller batches followed it.
 int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     DCN_HIP(hipStreamSynchronize(c->stream));
     if (needed_records) *needed_records = 0;
     if (c->profiling) DCN_TRY(prof_harvest(c));
     if (!c->batch_pending) return DCN_OK;
     c->batch_pending = false;
-    DCN_HIP(hipMemcpy(c->h_status, c->d_status, sizeof(dcn_status), hipMemcpyDeviceToHost));
-    if (c->h_status->rec_overflow) {
-        // size the retry for the fullest shard (shards fill unevenly)
-        uint64_t need = 0;
-        for (uint32_t sidx = 0; sidx < DCN_REC_SHARDS; ++sidx)
-            need = std::max<uint64_t>(need, c->h_status->rec_count[sidx]);
-        need *= DCN_REC_SHARDS;
+    DCN_HIP(hipMemcpy(c->h_report, c->d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost));
+    if (c->h_report->overflow) {
+        const uint64_t need = c->h_report->need;
+        DCN_HIP(hipMemset(c->d_report, 0, offsetof(dcn_batch_report, stats))); // re-arm
         if (needed_records) *needed_records = need;
-        return dcn_fail(DCN_ERR_CAPACITY, "hit-record scratch overflow: need " + std::to_string(need) +
-                                              " records, have " + std::to_string(c->rec_capacity) +
-                                              " (dcn_ctx_reserve_records)");
+        return overflow_error(c, need);
     }
     return DCN_OK;
 }
 
-// A few host threads that split one large memcpy: a single core moves ~10 GB/s into the pinned staging
-// buffer, which is less than the PCIe link takes out of it.  Process-wide, created on first use;
-// DCN_HOST_THREADS sets the width (default: up to 8, 1 = plain memcpy).
-class HostCopyPool {
+// A few host threads that split one large job (a copy or a pack) into slices: a single core moves ~10 GB/s into
+// the pinned staging buffer, which is less than the PCIe link takes out of it.  Process-wide, created on first
+// use; DCN_HOST_THREADS sets the width (default: up to 8, 1 = run inline).
+class HostPool {
   public:
-    static HostCopyPool &get() {
-        static HostCopyPool pool;
+    static HostPool &get() {
+        static HostPool pool;
         return pool;
     }
-    void copy(void *dst, const void *src, size_t n) {
-        if (n_threads_ <= 1 || n < (4u << 20)) {
-            memcpy(dst, src, n);
+    int width() const { return n_threads_; }
+    // fn(i, n): slice i of n
+    void run(const std::function<void(int, int)> &fn, bool small = false) {
+        if (n_threads_ <= 1 || small) {
+            fn(0, 1);
             return;
         }
-        std::lock_guard<std::mutex> user(user_mu_); // one copy at a time
+        std::lock_guard<std::mutex> user(user_mu_); // one job at a time
         {
             std::lock_guard<std::mutex> g(mu_);
-            dst_ = (uint8_t *)dst;
-            src_ = (const uint8_t *)src;
-            n_ = n;
+            fn_ = &fn;
             pending_ = n_threads_ - 1;
             ++generation_;
         }
         cv_.notify_all();
-        slice(0);
+        fn(0, n_threads_);
         std::unique_lock<std::mutex> g(mu_);
         done_cv_.wait(g, [&] { return pending_ == 0; });
     }
-    ~HostCopyPool() {
+    void copy(void *dst, const void *src, size_t n) {
+        run([&](int i, int nt) {
+            size_t per = ((n / nt) + 4095) & ~(size_t)4095;
+            size_t lo = std::min(n, per * i), hi = i == nt - 1 ? n : std::min(n, per * (i + 1));
+            if (hi > lo) memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo);
+        }, n < (4u << 20));
+    }
+    ~HostPool() {
         {
             std::lock_guard<std::mutex> g(mu_);
             stop_ = true;
@@ -588,28 +724,25 @@ class HostCopyPool {
     }
 
   private:
-    HostCopyPool() {
+    HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
         int want = (int)std::min<unsigned>(8, hw ? hw : 1);
         if (const char *e = getenv("DCN_HOST_THREADS")) want = atoi(e);
         n_threads_ = std::max(1, std::min(want, 64));
-        for (int i = 1; i < n_threads_; ++i) workers_.emplace_back([this, i] { run(i); });
+        for (int i = 1; i < n_threads_; ++i) workers_.emplace_back([this, i] { worker(i); });
     }
-    void slice(int i) {
-        size_t per = ((n_ / n_threads_) + 4095) & ~(size_t)4095;
-        size_t lo = std::min(n_, per * i), hi = i == n_threads_ - 1 ? n_ : std::min(n_, per * (i + 1));
-        if (hi > lo) memcpy(dst_ + lo, src_ + lo, hi - lo);
-    }
-    void run(int i) {
+    void worker(int i) {
         uint64_t seen = 0;
         for (;;) {
+            const std::function<void(int, int)> *fn;
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [&] { return stop_ || generation_ != seen; });
                 if (stop_) return;
                 seen = generation_;
+                fn = fn_;
             }
-            slice(i);
+            (*fn)(i, n_threads_);
             std::lock_guard<std::mutex> g(mu_);
             if (--pending_ == 0) done_cv_.notify_one();
         }
@@ -618,9 +751,7 @@ class HostCopyPool {
     std::vector<std::thread> workers_;
     std::mutex mu_, user_mu_;
     std::condition_variable cv_, done_cv_;
-    uint8_t *dst_ = nullptr;
-    const uint8_t *src_ = nullptr;
-    size_t n_ = 0;
+    const std::function<void(int, int)> *fn_ = nullptr;
     int pending_ = 0;
     uint64_t generation_ = 0;
     bool stop_ = false;
@@ -628,6 +759,7 @@ class HostCopyPool {
 
 // page-locked host memory (hipHostMalloc / hipHostRegister, e.g. from dcn_host_alloc) needs no staging
 bool is_pinned_host(const void *p) {
+    if (!p) return false;
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
         (void)hipGetLastError(); // plain malloc memory: not an error for us
@@ -636,46 +768,43 @@ bool is_pinned_host(const void *p) {
     return attr.type == hipMemoryTypeHost;
 }
 
-// copy `bytes` of host memory to device on the copy stream: directly when the source is page-locked,
-// otherwise through the two pinned staging buffers (the host fills one while the other is in flight)
-int staged_h2d(dcn_ctx *c, void *d_dst, const void *h_src, uint64_t bytes) {
-    const uint8_t *src = (const uint8_t *)h_src;
+// Copy `bytes` to the device on the copy stream.  Page-locked sources go straight over the link; anything else is
+// cut into pieces that pass through the ring of pinned staging buffers (the host fills one while earlier ones are
+// in flight).  `fill(dst, first, n)` produces bytes [first, first + n) of the payload in the staging buffer:
+// a (threaded) memcpy, or the host-side 2-bit pack.
+template <typename Fill>
+int staged_h2d_fill(dcn_ctx *c, void *d_dst, uint64_t bytes, uint64_t piece_align, Fill fill) {
     uint8_t *dst = (uint8_t *)d_dst;
-    if (bytes == 0) return DCN_OK;
-    if (is_pinned_host(h_src)) {
-        DCN_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->copy_stream));
-        return DCN_OK;
-    }
-    int which = 0;
-    for (uint64_t off = 0; off < bytes; off += c->stage_bytes, which ^= 1) {
-        uint64_t m = std::min<uint64_t>(c->stage_bytes, bytes - off);
+    const uint64_t piece = c->stage_bytes / piece_align * piece_align;
+    for (uint64_t off = 0; off < bytes; off += piece) {
+        const int which = c->stage_next;
+        c->stage_next = (which + 1) % dcn_ctx::N_STAGE;
+        const uint64_t m = std::min<uint64_t>(piece, bytes - off);
         DCN_HIP(hipEventSynchronize(c->stage_free[which])); // previous copy out of this buffer finished
-        HostCopyPool::get().copy(c->h_stage[which], src + off, m);
+        fill(c->h_stage[which], off, m);
         DCN_HIP(hipMemcpyAsync(dst + off, c->h_stage[which], m, hipMemcpyHostToDevice, c->copy_stream));
         DCN_HIP(hipEventRecord(c->stage_free[which], c->copy_stream));
     }
     return DCN_OK;
 }
 
-int validate_host_batch(const dcn_ctx *c, const uint64_t *offsets, const uint32_t *unit_id, uint32_t n_reads,
-                        uint32_t *n_units) {
-    if (n_reads > c->max_reads) return dcn_fail(DCN_ERR_CAPACITY, "n_reads exceeds the context's max_batch_reads");
-    if (offsets[0] != 0) return dcn_fail(DCN_ERR_ARG, "offsets[0] must be 0");
-    for (uint32_t r = 0; r < n_reads; ++r) {
-        if (offsets[r + 1] < offsets[r]) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
-        if (offsets[r + 1] - offsets[r] > 0xFFFFFFF0ull) return dcn_fail(DCN_ERR_ARG, "read longer than 2^32 bases");
+int staged_h2d(dcn_ctx *c, void *d_dst, const void *h_src, uint64_t bytes, int pinned = -1) {
+    if (bytes == 0) return DCN_OK;
+    if (pinned < 0) pinned = is_pinned_host(h_src) ? 1 : 0;
+    if (pinned) {
+        DCN_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        return DCN_OK;
     }
-    if (offsets[n_reads] > c->max_bases) return dcn_fail(DCN_ERR_CAPACITY, "batch exceeds the context's max_batch_bases");
-    if (unit_id) {
-        if (n_reads && unit_id[0] != 0) return dcn_fail(DCN_ERR_ARG, "unit_id[0] must be 0");
-        for (uint32_t r = 1; r < n_reads; ++r)
-            if (unit_id[r] != unit_id[r - 1] && unit_id[r] != unit_id[r - 1] + 1)
-                return dcn_fail(DCN_ERR_ARG, "unit_id must stay equal or grow by one");
-        *n_units = n_reads ? unit_id[n_reads - 1] + 1 : 0;
-    } else {
-        *n_units = n_reads;
-    }
-    return DCN_OK;
+    const uint8_t *src = (const uint8_t *)h_src;
+    return staged_h2d_fill(c, d_dst, bytes, 64, [&](uint8_t *stage, uint64_t first, uint64_t n) {
+        HostPool::get().copy(stage, src + first, n);
+    });
+}
+
+int slots_busy(const dcn_ctx *c) {
+    int n = 0;
+    for (const auto &sl : c->slots) n += sl.busy ? 1 : 0;
+    return n;
 }
 
 } // namespace
@@ -762,7 +891,7 @@ int dcn_load_index_fixed9(const char *path, int device, dcn_index **out, bool *h
     for (uint64_t off = 0; off < count && rc == DCN_OK; off += CH, which ^= 1) {
         const uint64_t m = std::min<uint64_t>(CH, count - off);
         if (!hip_ok(hipEventSynchronize(ev[which]), "event wait")) break; // the copy out of this buffer is done
-        HostCopyPool::get().copy(h_buf[which], src + 9 * off, 9 * m);
+        HostPool::get().copy(h_buf[which], src + 9 * off, 9 * m);
         if (!hip_ok(hipMemcpyAsync(d_raw[which], h_buf[which], 9 * m, hipMemcpyHostToDevice, st_), "hipMemcpyAsync")) break;
         rc = dcn_table_insert_varint9(idx, d_raw[which], m, d_new, d_flags, d_flags + 1, st_);
         if (rc == DCN_OK) hip_ok(hipEventRecord(ev[which], st_), "event record");
@@ -820,18 +949,27 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
         return dcn_fail(DCN_ERR_ARG, "batch limits imply more than 2^32 tiles");
     }
     c->max_tiles = (uint32_t)mt;
+    c->chunk_bases = 32ull << 20;
+    if (const char *cb = getenv("DCN_CHUNK_BASES")) {
+        long long v = atoll(cb);
+        if (v >= 1024) c->chunk_bases = (uint64_t)v;
+    }
     int rc = DCN_OK;
     auto fail = [&](int code) {
         free_ctx(c);
         return code;
     };
     if (hipSetDevice(c->device) != hipSuccess) return fail(dcn_fail(DCN_ERR_HIP, "hipSetDevice failed"));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->stage_free[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->stage_free[1], hipEventDisableTiming) != hipSuccess)
-        return fail(dcn_fail(DCN_ERR_HIP, "stream/event creation failed"));
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < dcn_ctx::N_STAGE; ++i)
+        ok = hipEventCreateWithFlags(&c->stage_free[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < dcn_ctx::N_EV; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return fail(dcn_fail(DCN_ERR_HIP, "stream/event creation failed"));
     uint64_t MR = max_batch_reads;
 #define A(ptr, count, what)                          \
     if ((rc = dev_alloc(&c->ptr, (count), what)) != DCN_OK) return fail(rc)
@@ -854,21 +992,23 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_caps, MR, "caps");
     A(d_set_off, MR + 1, "set_off");
     A(d_status, 1, "status");
+    A(d_report, 1, "report");
 #undef A
     // hit records: sized for the expected long-read density (1 minimizer per 8 windows, half of them hits),
     // grown on demand by the host API / dcn_ctx_reserve_records
     if ((rc = alloc_records(c, std::min<uint64_t>(std::max<uint64_t>(max_batch_bases / 16, 1u << 16), 1ull << 29))) != DCN_OK)
         return fail(rc);
-    c->stage_bytes = std::min<uint64_t>(std::max<uint64_t>(max_batch_bases, 4096), 32ull << 20);
-    for (int i = 0; i < 2; ++i)
+    c->stage_bytes = std::min<uint64_t>(std::max<uint64_t>(max_batch_bases + 64, 4096), 32ull << 20);
+    for (int i = 0; i < dcn_ctx::N_STAGE; ++i)
         if (hipHostMalloc((void **)&c->h_stage[i], c->stage_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(dcn_fail(DCN_ERR_NOMEM, "pinned staging allocation failed"));
-    if (hipHostMalloc((void **)&c->h_status, sizeof(dcn_status), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc((void **)&c->h_report, sizeof(dcn_batch_report), hipHostMallocDefault) != hipSuccess)
         return fail(dcn_fail(DCN_ERR_NOMEM, "pinned status allocation failed"));
     // zero padding in front of / behind the packed stream is written once; pack only touches the middle
     if (hipMemset(c->d_packed, 0, packed_words(max_batch_bases) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->d_invmask, 0, mask_words(max_batch_bases) * sizeof(uint32_t)) != hipSuccess ||
-        hipMemset(c->d_status, 0, sizeof(dcn_status)) != hipSuccess)
+        hipMemset(c->d_status, 0, sizeof(dcn_status)) != hipSuccess ||
+        hipMemset(c->d_report, 0, sizeof(dcn_batch_report)) != hipSuccess)
         return fail(dcn_fail(DCN_ERR_HIP, "hipMemset failed"));
     *out = c;
     return DCN_OK;
@@ -880,6 +1020,7 @@ extern "C" void *dcn_ctx_stream(dcn_ctx *ctx) { return ctx ? (void *)ctx->stream
 
 extern "C" int dcn_ctx_reserve_records(dcn_ctx *ctx, uint64_t n_records) {
     if (!ctx) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
+    if (slots_busy(ctx)) return dcn_fail(DCN_ERR_ARG, "host batches are in flight: wait for them first");
     DCN_HIP(hipSetDevice(ctx->device));
     DCN_HIP(hipStreamSynchronize(ctx->stream));
     if (n_records <= ctx->rec_capacity) return DCN_OK;
@@ -904,57 +1045,414 @@ extern "C" int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, con
     if (n_bases > ctx->max_bases) return dcn_fail(DCN_ERR_CAPACITY, "n_bases exceeds the context's max_batch_bases");
     if (n_units == 0 || n_units > n_reads || (!d_unit_id && n_units != n_reads))
         return dcn_fail(DCN_ERR_ARG, "n_units inconsistent with n_reads / d_unit_id");
+    // the packed stream of slot 0 is this path's pack target and a host batch's copy target
+    if (ctx->slots[0].busy) return dcn_fail(DCN_ERR_ARG, "a host batch is in flight on this context: wait for it first");
     DCN_HIP(hipSetDevice(ctx->device));
-    return enqueue_batch(ctx, d_bases, d_offsets, d_unit_id, n_reads, n_bases, n_units, params, d_keep, d_hits, d_total);
+    BatchView v;
+    v.d_ascii = d_bases;
+    v.d_packed = ctx->d_packed;
+    v.d_invmask = ctx->d_invmask;
+    v.d_offsets = d_offsets;
+    v.d_unit_id = d_unit_id;
+    v.n_reads = n_reads;
+    v.n_units = n_units;
+    v.b0 = 0;
+    v.b1 = n_bases;
+    v.d_keep = d_keep;
+    v.d_hits = d_hits;
+    v.d_total = d_total;
+    v.d_report = ctx->d_report;
+    DCN_TRY(enqueue_batch(ctx, v, params));
+    ctx->batch_pending = true;
+    return DCN_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------
+// host batches: submit / wait
+// ----------------------------------------------------------------------------------------------------
+bool dcn_host_pack_groups(const uint8_t *ascii, uint64_t n_bases, uint64_t g0, uint64_t g1, uint32_t *packed,
+                          uint32_t *mask); // host_pack.cpp; true: a '\n' byte was seen
+
+namespace {
+
+enum class Transport {
+    AsciiDirect, // page-locked ASCII: DMA as it is, pack on the device
+    AsciiStaged, // pageable ASCII copied into the pinned ring, pack on the device
+    HostPacked,  // pageable ASCII packed by the host threads INTO the pinned ring: 0.375 B/bp on the link
+    Packed,      // the caller hands over the 2-bit stream + mask
+};
+
+struct HostInput {
+    const uint8_t *bases = nullptr;    // ASCII, or null
+    const uint32_t *packed = nullptr;  // caller-packed stream (Transport::Packed)
+    const uint32_t *invmask = nullptr;
+    const uint64_t *offsets = nullptr;
+    const uint32_t *unit_id = nullptr;
+    uint32_t n_reads = 0;
+};
+
+int alloc_slot(dcn_ctx *c, int si) {
+    dcn_slot &sl = c->slots[si];
+    if (sl.allocated) return DCN_OK;
+    const uint64_t MR = c->max_reads;
+    if (si == 0) { // the context's own buffers
+        sl.d_ascii = c->d_ascii;
+        sl.d_packed = c->d_packed;
+        sl.d_invmask = c->d_invmask;
+        sl.d_offsets = c->d_offsets;
+        sl.d_unit_id = c->d_unit_id;
+        sl.d_keep = c->d_keep;
+        sl.d_hits = c->d_hits;
+        sl.d_total = c->d_total;
+        sl.owns_buffers = false;
+    } else {
+        sl.owns_buffers = true;
+        DCN_TRY(dev_alloc(&sl.d_ascii, c->max_bases + 64, "slot ascii"));
+        DCN_TRY(dev_alloc(&sl.d_packed, packed_words(c->max_bases), "slot packed"));
+        DCN_TRY(dev_alloc(&sl.d_invmask, mask_words(c->max_bases), "slot invmask"));
+        DCN_TRY(dev_alloc(&sl.d_offsets, MR + 1, "slot offsets"));
+        DCN_TRY(dev_alloc(&sl.d_unit_id, MR, "slot unit_id"));
+        DCN_TRY(dev_alloc(&sl.d_keep, MR, "slot keep"));
+        DCN_TRY(dev_alloc(&sl.d_hits, MR, "slot hits"));
+        DCN_TRY(dev_alloc(&sl.d_total, MR, "slot total"));
+        DCN_HIP(hipMemset(sl.d_packed, 0, packed_words(c->max_bases) * sizeof(uint32_t)));
+        DCN_HIP(hipMemset(sl.d_invmask, 0, mask_words(c->max_bases) * sizeof(uint32_t)));
+    }
+    DCN_TRY(dev_alloc(&sl.d_report, 1, "slot report"));
+    DCN_HIP(hipHostMalloc((void **)&sl.h_report, sizeof(dcn_batch_report), hipHostMallocDefault));
+    DCN_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    sl.allocated = true;
+    return DCN_OK;
+}
+
+template <typename T>
+int ensure_pinned(T **p, uint64_t count) {
+    if (*p) return DCN_OK;
+    hipError_t e = hipHostMalloc((void **)p, std::max<uint64_t>(count, 1) * sizeof(T), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return dcn_fail(DCN_ERR_NOMEM, std::string("pinned result staging: ") + hipGetErrorString(e));
+    }
+    return DCN_OK;
+}
+
+// Validates reads [r0, ...) of the batch and returns the end of the chunk that starts at r0: the first unit
+// boundary at which the chunk holds at least chunk_bases bases (or the end of the batch).
+int next_chunk(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t n_bases_total, uint32_t *r1_out) {
+    const uint64_t *off = in.offsets;
+    const uint32_t *uid = in.unit_id;
+    const uint64_t b0 = off[r0], target = b0 + c->chunk_bases;
+    uint32_t r = r0;
+    for (;;) {
+        if (off[r + 1] < off[r]) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
+        if (off[r + 1] - off[r] > 0xFFFFFFF0ull) return dcn_fail(DCN_ERR_ARG, "read longer than 2^32 bases");
+        if (off[r + 1] > n_bases_total) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
+        ++r;
+        if (r == in.n_reads) break;
+        if (uid) {
+            if (uid[r] != uid[r - 1] && uid[r] != uid[r - 1] + 1)
+                return dcn_fail(DCN_ERR_ARG, "unit_id must stay equal or grow by one");
+            if (uid[r] == uid[r - 1]) continue; // mates stay together
+        }
+        if (off[r] >= target) break;
+    }
+    *r1_out = r;
+    return DCN_OK;
+}
+
+// kernels + result copies of one chunk (its inputs are on the device, or on their way on the copy stream)
+int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, const dcn_chunk &ch, bool wait_h2d) {
+    const int e = c->ev_next;
+    c->ev_next = (e + 1) % dcn_ctx::N_EV;
+    if (wait_h2d) {
+        DCN_HIP(hipEventRecord(c->ev_h2d[e], c->copy_stream));
+        DCN_HIP(hipStreamWaitEvent(c->stream, c->ev_h2d[e], 0));
+    }
+    BatchView v;
+    v.d_ascii = sl.device_pack ? sl.d_ascii : nullptr;
+    v.d_packed = sl.d_packed;
+    v.d_invmask = sl.d_invmask;
+    v.d_offsets = sl.d_offsets + ch.r0;
+    v.d_unit_id = sl.has_units ? sl.d_unit_id + ch.r0 : nullptr;
+    v.unit_base = ch.u0;
+    v.n_reads = ch.r1 - ch.r0;
+    v.n_units = ch.u1 - ch.u0;
+    // ASCII chunks are copied and packed in whole 32-base groups (see submit_impl)
+    v.b0 = ch.b0 / 32 * 32;
+    v.b1 = std::min<uint64_t>((ch.b1 + 31) / 32 * 32, sl.n_bases);
+    v.d_keep = sl.d_keep + ch.u0;
+    v.d_hits = sl.counts ? sl.d_hits + ch.u0 : nullptr;
+    v.d_total = sl.counts ? sl.d_total + ch.u0 : nullptr;
+    v.d_report = sl.d_report;
+    DCN_TRY(enqueue_batch(c, v, &sl.params));
+    DCN_HIP(hipEventRecord(c->ev_comp[e], c->stream));
+    DCN_HIP(hipStreamWaitEvent(c->d2h_stream, c->ev_comp[e], 0));
+    const uint32_t nu = ch.u1 - ch.u0;
+    DCN_HIP(hipMemcpyAsync((sl.keep_direct ? sl.u_keep : sl.h_keep) + ch.u0, sl.d_keep + ch.u0, nu, hipMemcpyDeviceToHost,
+                           c->d2h_stream));
+    if (sl.u_hits)
+        DCN_HIP(hipMemcpyAsync((sl.hits_direct ? sl.u_hits : sl.h_hits) + ch.u0, sl.d_hits + ch.u0,
+                               (uint64_t)nu * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h_stream));
+    if (sl.u_total)
+        DCN_HIP(hipMemcpyAsync((sl.total_direct ? sl.u_total : sl.h_total) + ch.u0, sl.d_total + ch.u0,
+                               (uint64_t)nu * sizeof(uint32_t), hipMemcpyDeviceToHost, c->d2h_stream));
+    return DCN_OK;
+}
+
+int finish_submission(dcn_ctx *c, dcn_slot &sl) {
+    DCN_HIP(hipMemcpyAsync(sl.h_report, sl.d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost, c->d2h_stream));
+    DCN_HIP(hipEventRecord(sl.done, c->d2h_stream));
+    return DCN_OK;
+}
+
+// after a failure in the middle of a submission: nothing of this context may still be running when the caller's
+// buffers go away
+void drain(dcn_ctx *c) {
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->d2h_stream);
+}
+
+int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8_t *keep, uint32_t *hits,
+                uint32_t *total, uint64_t *ticket) {
+    if (!c) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
+    if (!ticket) return dcn_fail(DCN_ERR_ARG, "ticket is NULL");
+    *ticket = 0;
+    DCN_TRY(check_params(params));
+    if (in.n_reads > 0 && (!in.offsets || !keep)) return dcn_fail(DCN_ERR_ARG, "offsets/keep is NULL");
+    if (in.n_reads > c->max_reads) return dcn_fail(DCN_ERR_CAPACITY, "n_reads exceeds the context's max_batch_reads");
+    if (c->batch_pending) return dcn_fail(DCN_ERR_ARG, "device-pointer batches are pending: dcn_ctx_synchronize first");
+    int si = -1;
+    for (int i = 0; i < dcn_ctx::N_SLOTS && si < 0; ++i)
+        if (!c->slots[i].busy) si = i;
+    if (si < 0) return dcn_fail(DCN_ERR_CAPACITY, "two batches are already in flight: dcn_filter_batch_wait first");
+    DCN_HIP(hipSetDevice(c->device));
+    DCN_TRY(alloc_slot(c, si));
+    dcn_slot &sl = c->slots[si];
+    const uint32_t n_reads = in.n_reads;
+    uint64_t n_bases = 0;
+    uint32_t n_units = 0;
+    if (n_reads) {
+        if (in.offsets[0] != 0) return dcn_fail(DCN_ERR_ARG, "offsets[0] must be 0");
+        n_bases = in.offsets[n_reads];
+        if (n_bases > c->max_bases) return dcn_fail(DCN_ERR_CAPACITY, "batch exceeds the context's max_batch_bases");
+        if (in.unit_id && in.unit_id[0] != 0) return dcn_fail(DCN_ERR_ARG, "unit_id[0] must be 0");
+        const bool packed_in = in.packed != nullptr;
+        if (n_bases > 0 && !packed_in && !in.bases) return dcn_fail(DCN_ERR_ARG, "bases is NULL");
+        if (n_bases > 0 && packed_in && !in.invmask) return dcn_fail(DCN_ERR_ARG, "invmask is NULL");
+    }
+    static const bool host_pack_ok = !getenv("DCN_NO_HOST_PACK");
+    Transport tr;
+    if (in.packed) tr = Transport::Packed;
+    else if (is_pinned_host(in.bases)) tr = Transport::AsciiDirect;
+    else tr = host_pack_ok ? Transport::HostPacked : Transport::AsciiStaged;
+
+    sl.params = *params;
+    sl.counts = hits || total;
+    sl.has_units = in.unit_id != nullptr;
+    sl.n_reads = n_reads;
+    sl.n_bases = n_bases;
+    sl.u_keep = keep;
+    sl.u_hits = hits;
+    sl.u_total = total;
+    sl.keep_direct = is_pinned_host(keep);
+    sl.hits_direct = hits && is_pinned_host(hits);
+    sl.total_direct = total && is_pinned_host(total);
+    if (!sl.keep_direct) DCN_TRY(ensure_pinned(&sl.h_keep, c->max_reads));
+    if (hits && !sl.hits_direct) DCN_TRY(ensure_pinned(&sl.h_hits, c->max_reads));
+    if (total && !sl.total_direct) DCN_TRY(ensure_pinned(&sl.h_total, c->max_reads));
+    const int off_pinned = is_pinned_host(in.offsets) ? 1 : 0, uid_pinned = is_pinned_host(in.unit_id) ? 1 : 0;
+    const int pk_pinned = in.packed ? ((is_pinned_host(in.packed) && is_pinned_host(in.invmask)) ? 1 : 0) : 0;
+
+    for (int attempt = 0;; ++attempt) {
+        sl.device_pack = tr == Transport::AsciiDirect || tr == Transport::AsciiStaged;
+        sl.chunks.clear();
+        DCN_HIP(hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream));
+        bool saw_newline = false;
+        int rc = DCN_OK;
+        uint32_t r0 = 0, u0 = 0;
+        uint64_t groups_done = 0; // 32-base groups of the stream already sent (HostPacked / Packed)
+        while (r0 < n_reads && rc == DCN_OK) {
+            dcn_chunk ch;
+            ch.r0 = r0;
+            ch.u0 = u0;
+            if ((rc = next_chunk(c, in, r0, n_bases, &ch.r1)) != DCN_OK) break;
+            ch.u1 = in.unit_id ? (ch.r1 == n_reads ? in.unit_id[n_reads - 1] + 1 : in.unit_id[ch.r1]) : ch.r1;
+            ch.b0 = in.offsets[ch.r0];
+            ch.b1 = in.offsets[ch.r1];
+            auto copies = [&]() -> int {
+                if (ch.b1 > ch.b0) {
+                    if (sl.device_pack) {
+                        // whole 32-base groups, so that the device pack of the groups two chunks share is right
+                        // whichever of them runs last
+                        const uint64_t a0 = ch.b0 / 32 * 32, a1 = std::min<uint64_t>((ch.b1 + 31) / 32 * 32, n_bases);
+                        DCN_TRY(staged_h2d(c, sl.d_ascii + a0, in.bases + a0, a1 - a0, tr == Transport::AsciiDirect ? 1 : 0));
+                    } else {
+                        // groups not sent yet, up to the one holding this chunk's last base
+                        const uint64_t g0 = groups_done, g1 = (ch.b1 + 31) / 32;
+                        if (g1 > g0) {
+                            uint32_t *dp = sl.d_packed + DCN_FRONT_PAD + 2 * g0, *dm = sl.d_invmask + DCN_FRONT_PAD + g0;
+                            if (tr == Transport::Packed) {
+                                DCN_TRY(staged_h2d(c, dp, in.packed + 2 * g0, (g1 - g0) * 8, pk_pinned));
+                                DCN_TRY(staged_h2d(c, dm, in.invmask + g0, (g1 - g0) * 4, pk_pinned));
+                            } else {
+                                // pieces of whole groups: 8 bytes of stream + 4 of mask per group, side by side in a
+                                // staging buffer, packed there by the host threads
+                                const uint64_t per_piece = c->stage_bytes / 12 / 64 * 64;
+                                for (uint64_t g = g0; g < g1; g += per_piece) {
+                                    const uint64_t m = std::min<uint64_t>(per_piece, g1 - g);
+                                    const int which = c->stage_next;
+                                    c->stage_next = (which + 1) % dcn_ctx::N_STAGE;
+                                    DCN_HIP(hipEventSynchronize(c->stage_free[which]));
+                                    uint32_t *hp = (uint32_t *)c->h_stage[which], *hm = hp + 2 * m;
+                                    std::atomic<bool> nl(false);
+                                    HostPool::get().run([&](int i, int nt) {
+                                        const uint64_t per = (m + nt - 1) / nt, lo = std::min<uint64_t>(m, per * i),
+                                                       hi = std::min<uint64_t>(m, lo + per);
+                                        if (hi <= lo) return;
+                                        // a '\n' anywhere means some read may end in one (src/filter_common.rs:229 strips
+                                        // it): only the device path probes read ends, so the batch is sent again as ASCII
+                                        if (dcn_host_pack_groups(in.bases, n_bases, g + lo, g + hi, hp + 2 * lo, hm + lo))
+                                            nl.store(true);
+                                    }, m < 4096);
+                                    saw_newline = saw_newline || nl.load();
+                                    DCN_HIP(hipMemcpyAsync(dp + 2 * (g - g0), hp, m * 8, hipMemcpyHostToDevice, c->copy_stream));
+                                    DCN_HIP(hipMemcpyAsync(dm + (g - g0), hm, m * 4, hipMemcpyHostToDevice, c->copy_stream));
+                                    DCN_HIP(hipEventRecord(c->stage_free[which], c->copy_stream));
+                                }
+                            }
+                            groups_done = g1;
+                        }
+                    }
+                }
+                DCN_TRY(staged_h2d(c, sl.d_offsets + ch.r0, in.offsets + ch.r0, (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t), off_pinned));
+                if (in.unit_id)
+                    DCN_TRY(staged_h2d(c, sl.d_unit_id + ch.r0, in.unit_id + ch.r0, (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t), uid_pinned));
+                return DCN_OK;
+            };
+            if ((rc = copies()) != DCN_OK) break;
+            if (saw_newline) break; // this attempt is abandoned
+            if ((rc = enqueue_chunk(c, sl, ch, true)) != DCN_OK) break;
+            sl.chunks.push_back(ch);
+            r0 = ch.r1;
+            u0 = ch.u1;
+        }
+        n_units = u0;
+        if (rc == DCN_OK && saw_newline && attempt == 0) {
+            drain(c);
+            tr = Transport::AsciiStaged;
+            continue;
+        }
+        if (rc != DCN_OK) {
+            drain(c);
+            return rc;
+        }
+        break;
+    }
+    sl.n_units = n_units;
+    int rc = finish_submission(c, sl);
+    if (rc != DCN_OK) {
+        drain(c);
+        return rc;
+    }
+    sl.busy = true;
+    sl.ticket = c->next_ticket++;
+    *ticket = sl.ticket;
+    return DCN_OK;
+}
+
+int wait_impl(dcn_ctx *c, uint64_t ticket) {
+    if (!c) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
+    dcn_slot *slp = nullptr;
+    for (auto &s : c->slots)
+        if (s.busy && s.ticket == ticket) slp = &s;
+    if (!slp) return dcn_fail(DCN_ERR_ARG, "no batch with this ticket is in flight");
+    dcn_slot &sl = *slp;
+    DCN_HIP(hipSetDevice(c->device));
+    auto fail = [&](int rc) {
+        drain(c);
+        sl.busy = false;
+        return rc;
+    };
+    for (int attempt = 0;; ++attempt) {
+        hipError_t e = hipEventSynchronize(sl.done);
+        if (e != hipSuccess) return fail(dcn_fail(DCN_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e)));
+        if (!sl.h_report->overflow) break;
+        // Some chunk dropped hit records.  Grow the scratch and run the batch's kernels again: its inputs are still
+        // resident in the slot.  Everything else in flight is drained first, since the scratch is shared.
+        const uint64_t need = sl.h_report->need;
+        if (attempt >= 3) return fail(overflow_error(c, need));
+        drain(c);
+        uint64_t want = std::max<uint64_t>(need + need / 8 + 1024, c->rec_capacity * 2);
+        int rc = alloc_records(c, std::min<uint64_t>(want, 1ull << 29));
+        if (rc != DCN_OK) return fail(rc);
+        if (hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream) != hipSuccess)
+            return fail(dcn_fail(DCN_ERR_HIP, "hipMemsetAsync failed"));
+        for (const dcn_chunk &ch : sl.chunks)
+            if ((rc = enqueue_chunk(c, sl, ch, false)) != DCN_OK) return fail(rc);
+        if ((rc = finish_submission(c, sl)) != DCN_OK) return fail(rc);
+    }
+    if (!sl.keep_direct && sl.n_units) memcpy(sl.u_keep, sl.h_keep, sl.n_units);
+    if (sl.u_hits && !sl.hits_direct && sl.n_units) memcpy(sl.u_hits, sl.h_hits, (uint64_t)sl.n_units * sizeof(uint32_t));
+    if (sl.u_total && !sl.total_direct && sl.n_units) memcpy(sl.u_total, sl.h_total, (uint64_t)sl.n_units * sizeof(uint32_t));
+    for (int i = 0; i < DCN_N_STATS; ++i) c->host_stats[i] += sl.h_report->stats[i];
+    sl.busy = false;
+    return DCN_OK;
+}
+
+} // namespace
+
+extern "C" int dcn_filter_batch_submit(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
+                                       uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
+                                       uint32_t *total, uint64_t *ticket) {
+    HostInput in;
+    in.bases = bases;
+    in.offsets = offsets;
+    in.unit_id = unit_id;
+    in.n_reads = n_reads;
+    return submit_impl(ctx, in, params, keep, hits, total, ticket);
+}
+
+extern "C" int dcn_filter_batch_packed_submit(dcn_ctx *ctx, const uint32_t *packed, const uint32_t *invmask,
+                                              const uint64_t *offsets, const uint32_t *unit_id, uint32_t n_reads,
+                                              const dcn_params *params, uint8_t *keep, uint32_t *hits, uint32_t *total,
+                                              uint64_t *ticket) {
+    if (n_reads > 0 && !packed) return dcn_fail(DCN_ERR_ARG, "packed is NULL");
+    HostInput in;
+    in.packed = packed;
+    in.invmask = invmask;
+    in.offsets = offsets;
+    in.unit_id = unit_id;
+    in.n_reads = n_reads;
+    return submit_impl(ctx, in, params, keep, hits, total, ticket);
+}
+
+extern "C" int dcn_filter_batch_wait(dcn_ctx *ctx, uint64_t ticket) { return wait_impl(ctx, ticket); }
 
 extern "C" int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
                                 uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
                                 uint32_t *total) {
-    if (!ctx) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
-    auto t_enter = std::chrono::steady_clock::now();
-    DCN_TRY(check_params(params));
-    if (n_reads == 0) return DCN_OK;
-    if (!offsets || !keep) return dcn_fail(DCN_ERR_ARG, "offsets/keep is NULL");
-    uint32_t n_units = 0;
-    DCN_TRY(validate_host_batch(ctx, offsets, unit_id, n_reads, &n_units));
-    uint64_t n_bases = offsets[n_reads];
-    if (n_bases > 0 && !bases) return dcn_fail(DCN_ERR_ARG, "bases is NULL");
-    DCN_HIP(hipSetDevice(ctx->device));
-    static const bool timing = getenv("DCN_HOST_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
-    auto t_stage = now();
-    // stage inputs on the copy stream; the compute stream waits for the last copy
-    DCN_TRY(staged_h2d(ctx, ctx->d_ascii, bases, n_bases));
-    DCN_TRY(staged_h2d(ctx, ctx->d_offsets, offsets, (uint64_t)(n_reads + 1) * sizeof(uint64_t)));
-    if (unit_id) DCN_TRY(staged_h2d(ctx, ctx->d_unit_id, unit_id, (uint64_t)n_reads * sizeof(uint32_t)));
-    DCN_HIP(hipEventRecord(ctx->copy_done, ctx->copy_stream));
-    DCN_HIP(hipStreamWaitEvent(ctx->stream, ctx->copy_done, 0));
-    auto t_run = now();
-    for (int attempt = 0;; ++attempt) {
-        // without hit counts / totals the kernels only have to fix the decisions (early-out, see enqueue_batch)
-        DCN_TRY(enqueue_batch(ctx, ctx->d_ascii, ctx->d_offsets, unit_id ? ctx->d_unit_id : nullptr, n_reads, n_bases,
-                              n_units, params, ctx->d_keep, (hits || total) ? ctx->d_hits : nullptr,
-                              (hits || total) ? ctx->d_total : nullptr));
-        uint64_t need = 0;
-        int rc = sync_and_check(ctx, &need);
-        if (rc == DCN_OK) break;
-        if (rc != DCN_ERR_CAPACITY || attempt >= 3) return rc;
-        // grow the record scratch and run the batch again (inputs are still resident)
-        uint64_t want = std::max<uint64_t>(need + need / 8 + 1024, ctx->rec_capacity * 2);
-        DCN_TRY(alloc_records(ctx, std::min<uint64_t>(want, 1ull << 29)));
-        // (the finish kernel skips the counters of an overflowed attempt, so nothing is double counted)
-    }
-    auto t_back = now();
-    DCN_HIP(hipMemcpy(keep, ctx->d_keep, n_units, hipMemcpyDeviceToHost));
-    if (hits) DCN_HIP(hipMemcpy(hits, ctx->d_hits, (uint64_t)n_units * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (total) DCN_HIP(hipMemcpy(total, ctx->d_total, (uint64_t)n_units * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (timing)
-        fprintf(stderr, "dcn_filter_batch: validate %.2f ms, stage+enqueue copies %.2f ms, copies drain+kernels %.2f ms, "
-                        "results back %.2f ms\n", ms(t_enter, t_stage), ms(t_stage, t_run), ms(t_run, t_back), ms(t_back, now()));
+    uint64_t ticket = 0;
+    DCN_TRY(dcn_filter_batch_submit(ctx, bases, offsets, unit_id, n_reads, params, keep, hits, total, &ticket));
+    return wait_impl(ctx, ticket);
+}
+
+extern "C" int dcn_filter_batch_packed(dcn_ctx *ctx, const uint32_t *packed, const uint32_t *invmask,
+                                       const uint64_t *offsets, const uint32_t *unit_id, uint32_t n_reads,
+                                       const dcn_params *params, uint8_t *keep, uint32_t *hits, uint32_t *total) {
+    uint64_t ticket = 0;
+    DCN_TRY(dcn_filter_batch_packed_submit(ctx, packed, invmask, offsets, unit_id, n_reads, params, keep, hits, total,
+                                           &ticket));
+    return wait_impl(ctx, ticket);
+}
+
+extern "C" int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uint32_t *invmask) {
+    if (n_bases > 0 && (!bases || !packed || !invmask)) return dcn_fail(DCN_ERR_ARG, "bases/packed/invmask is NULL");
+    const uint64_t G = (n_bases + 31) / 32;
+    HostPool::get().run([&](int i, int nt) {
+        const uint64_t per = (G + nt - 1) / nt, lo = std::min<uint64_t>(G, per * i), hi = std::min<uint64_t>(G, lo + per);
+        dcn_host_pack_groups(bases, n_bases, lo, hi, packed + 2 * lo, invmask + lo);
+    }, G < 4096);
     return DCN_OK;
 }
 
@@ -986,17 +1484,23 @@ extern "C" int dcn_ctx_set_profiling(dcn_ctx *ctx, int enable) {
 
 extern "C" int dcn_ctx_profile(dcn_ctx *ctx, double stage_ms[DCN_N_STAGES], uint64_t *n_batches) {
     if (!ctx || !stage_ms) return dcn_fail(DCN_ERR_ARG, "ctx/stage_ms is NULL");
+    if (ctx->profiling) { // waits for the runs marked so far
+        DCN_HIP(hipSetDevice(ctx->device));
+        DCN_TRY(prof_harvest(ctx));
+    }
     for (int j = 0; j < DCN_N_STAGES; ++j) stage_ms[j] = ctx->prof_ms[j];
     if (n_batches) *n_batches = ctx->prof_batches;
     return DCN_OK;
 }
 
+// counters = completed host batches (summed on the host when each batch is waited for) + everything the
+// device-pointer API has enqueued (accumulated on the device)
 extern "C" int dcn_ctx_stats(dcn_ctx *ctx, uint64_t counters[DCN_N_STATS]) {
     if (!ctx || !counters) return dcn_fail(DCN_ERR_ARG, "ctx/counters is NULL");
     DCN_HIP(hipSetDevice(ctx->device));
     DCN_HIP(hipStreamSynchronize(ctx->stream));
-    DCN_HIP(hipMemcpy(ctx->h_status, ctx->d_status, sizeof(dcn_status), hipMemcpyDeviceToHost));
-    for (int i = 0; i < DCN_N_STATS; ++i) counters[i] = ctx->h_status->stats[i];
+    DCN_HIP(hipMemcpy(ctx->h_report, ctx->d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost));
+    for (int i = 0; i < DCN_N_STATS; ++i) counters[i] = ctx->h_report->stats[i] + ctx->host_stats[i];
     return DCN_OK;
 }
 
@@ -1004,9 +1508,38 @@ extern "C" int dcn_ctx_reset_stats(dcn_ctx *ctx) {
     if (!ctx) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
     DCN_HIP(hipSetDevice(ctx->device));
     DCN_HIP(hipStreamSynchronize(ctx->stream));
-    DCN_HIP(hipMemset(ctx->d_status->stats, 0, sizeof(unsigned long long) * DCN_N_STATS));
+    DCN_HIP(hipMemset(ctx->d_report->stats, 0, sizeof(unsigned long long) * DCN_N_STATS));
+    for (int i = 0; i < DCN_N_STATS; ++i) ctx->host_stats[i] = 0;
     return DCN_OK;
 }
+
+// Sum of the six counters over several contexts: the merge the reference does when its worker threads finish
+// (ProcessingStats, src/local_filter.rs:388-396).  All contexts live in this process, one per device or several per
+// device, so the sum is taken on the host; ranks in separate processes reduce with RCCL instead.
+extern "C" int dcn_stats_allreduce(dcn_ctx *const *ctxs, int n_ctx, uint64_t counters[DCN_N_STATS]) {
+    if (!counters || (n_ctx > 0 && !ctxs) || n_ctx < 0) return dcn_fail(DCN_ERR_ARG, "ctxs/counters is NULL");
+    for (int i = 0; i < DCN_N_STATS; ++i) counters[i] = 0;
+    for (int j = 0; j < n_ctx; ++j) {
+        uint64_t one[DCN_N_STATS];
+        DCN_TRY(dcn_ctx_stats(ctxs[j], one));
+        for (int i = 0; i < DCN_N_STATS; ++i) counters[i] += one[i];
+    }
+    return DCN_OK;
+}
+
+namespace {
+int validate_host_batch(const dcn_ctx *c, const uint64_t *offsets, uint32_t n_reads) {
+    if (n_reads > c->max_reads) return dcn_fail(DCN_ERR_CAPACITY, "n_reads exceeds the context's max_batch_reads");
+    if (slots_busy(c) || c->batch_pending) return dcn_fail(DCN_ERR_ARG, "batches are in flight on this context: wait for them first");
+    if (offsets[0] != 0) return dcn_fail(DCN_ERR_ARG, "offsets[0] must be 0");
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        if (offsets[r + 1] < offsets[r]) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
+        if (offsets[r + 1] - offsets[r] > 0xFFFFFFF0ull) return dcn_fail(DCN_ERR_ARG, "read longer than 2^32 bases");
+    }
+    if (offsets[n_reads] > c->max_bases) return dcn_fail(DCN_ERR_CAPACITY, "batch exceeds the context's max_batch_bases");
+    return DCN_OK;
+}
+} // namespace
 
 // ----------------------------------------------------------------------------------------------------
 // minimizer dump (parity / debugging seam)
@@ -1018,8 +1551,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     out_offsets[0] = 0;
     if (n_reads == 0) return DCN_OK;
     if (!offsets) return dcn_fail(DCN_ERR_ARG, "offsets is NULL");
-    uint32_t n_units = 0;
-    DCN_TRY(validate_host_batch(ctx, offsets, nullptr, n_reads, &n_units));
+    DCN_TRY(validate_host_batch(ctx, offsets, n_reads));
     uint64_t n_bases = offsets[n_reads];
     if (n_bases > 0 && !bases) return dcn_fail(DCN_ERR_ARG, "bases is NULL");
     dcn_ctx *c = ctx;
@@ -1035,9 +1567,9 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     DCN_HIP(hipEventRecord(c->copy_done, c->copy_stream));
     DCN_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0));
     hipStream_t st = c->stream;
-    DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
+    DCN_HIP(hipMemsetAsync(c->d_status, 0, sizeof(dcn_status), st));
     uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
-    DCN_TRY(dcn_launch_pack(c->d_ascii, n_bases, packed, invmask, st));
+    DCN_TRY(dcn_launch_pack(c->d_ascii, 0, n_bases, packed, invmask, c->d_status, st));
     dcn_plan_args pa = {};
     pa.ascii = c->d_ascii;
     pa.offsets = c->d_offsets;
@@ -1123,6 +1655,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
     if (n_units == 0) return DCN_OK;
     if (!hash_offsets || !keep) return dcn_fail(DCN_ERR_ARG, "hash_offsets/keep is NULL");
     if (n_units > ctx->max_reads) return dcn_fail(DCN_ERR_CAPACITY, "n_units exceeds the context's max_batch_reads");
+    if (slots_busy(ctx) || ctx->batch_pending) return dcn_fail(DCN_ERR_ARG, "batches are in flight on this context: wait for them first");
     if (hash_offsets[0] != 0) return dcn_fail(DCN_ERR_ARG, "hash_offsets[0] must be 0");
     for (uint32_t u = 0; u < n_units; ++u) {
         if (hash_offsets[u + 1] < hash_offsets[u]) return dcn_fail(DCN_ERR_ARG, "hash_offsets must be non-decreasing");
@@ -1145,7 +1678,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         hipStream_t st = c->stream;
         DCN_HIP(hipMemcpyAsync(d_hashes, hashes, n_hashes * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         DCN_HIP(hipMemcpyAsync(d_hoff, hash_offsets, ((uint64_t)n_units + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
+        DCN_HIP(hipMemsetAsync(c->d_status, 0, sizeof(dcn_status), st));
         DCN_HIP(hipMemsetAsync(c->d_unit_state, 0, n_units, st));
         DCN_HIP(hipMemsetAsync(c->d_unit_scratch, 0, (uint64_t)c->max_reads * 4 * sizeof(uint32_t), st));
         uint32_t *g_total = c->d_unit_scratch, *g_hitcnt = g_total + c->max_reads,
@@ -1190,7 +1723,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         fa.keep = c->d_keep;
         fa.hits = c->d_hits;
         fa.total = c->d_total;
-        fa.status_stats = c->d_status->stats;
+        fa.report = c->d_report;
         fa.status = c->d_status;
         DCN_TRY(dcn_launch_finish(fa, st));
         c->batch_pending = true;
@@ -1247,10 +1780,10 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             DCN_HIP(hipEventRecord(c->copy_done, c->copy_stream));
             DCN_HIP(hipStreamWaitEvent(c->stream, c->copy_done, 0));
             hipStream_t st = c->stream;
-            DCN_HIP(hipMemsetAsync(c->d_status, 0, offsetof(dcn_status, stats), st));
+            DCN_HIP(hipMemsetAsync(c->d_status, 0, sizeof(dcn_status), st));
             DCN_HIP(hipMemsetAsync(c->d_dump_valid, 0, nb + 2, st));
             uint32_t *packed = c->d_packed + DCN_FRONT_PAD, *invmask = c->d_invmask + DCN_FRONT_PAD;
-            DCN_TRY(dcn_launch_pack(c->d_ascii, nb, packed, invmask, st, /*index_side=*/true));
+            DCN_TRY(dcn_launch_pack(c->d_ascii, 0, nb, packed, invmask, nullptr, st, /*index_side=*/true));
             dcn_plan_args pa = {};
             pa.ascii = c->d_ascii;
             pa.offsets = c->d_offsets;

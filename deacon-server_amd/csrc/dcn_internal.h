@@ -75,7 +75,10 @@ constexpr int DCN_WAVE = 64;           // one wave per workgroup in the scan ker
 constexpr int DCN_LCAP = 40;           // per-lane emitted-position list capacity between flushes
 constexpr uint32_t DCN_FRONT_PAD = 64; // u32 words of zero padding in front of the packed stream
 constexpr uint32_t DCN_TAIL_PAD = 256; // u32 words after it (lanes over-read past short tiles)
-constexpr uint32_t DCN_MAX_TILE_WINDOWS = 4096;
+// A lane scans as many steps as the longest tile of its wave, plus k-1 bases and one prefetched block: a short last
+// tile next to a full one over-reads by up to tile_windows + l + 32 bases.  The 256-word tail pad (4096 bases of the
+// packed stream, 8192 of the mask) covers that up to 2048 windows per tile.
+constexpr uint32_t DCN_MAX_TILE_WINDOWS = 2048;
 
 // one tile = up to `tile_windows` consecutive windows of one read, scanned by one lane
 struct dcn_tile {
@@ -90,15 +93,24 @@ struct dcn_tile {
 // counter (workgroup b appends to shard b % DCN_REC_SHARDS): one global word takes only ~88 atomics/us.
 constexpr uint32_t DCN_REC_SHARDS = 64;
 
-// status words written by the device pipeline (one per ctx, zeroed per batch)
+// status words written by the device pipeline (one per ctx, zeroed before every enqueued batch / chunk)
 struct dcn_status {
     unsigned long long rec_count[DCN_REC_SHARDS]; // hit records appended per shard (may exceed the segment size)
     uint32_t rec_overflow;                        // records dropped: a segment of the record buffer was too small
     uint32_t n_tiles;
     uint32_t any_records;                         // some kernel appended a hit record: the distinct pass has work
-    uint32_t reserved;
+    uint32_t any_newline;                         // the pack kernel saw a '\n' byte: only then does planning probe read ends
     unsigned long long set_cursor;                // distinct pass: slots handed out to the per-unit hash sets
-    unsigned long long stats[DCN_N_STATS];
+};
+
+// What survives the per-chunk clearing of dcn_status: one per host batch in flight, one per context for the
+// device-pointer API.  Read back when the batch is waited for / the context is synchronised.
+struct dcn_batch_report {
+    uint32_t overflow;                     // a chunk dropped hit records: its multi-wave units were decided from
+                                           // truncated records and its counters were skipped
+    uint32_t reserved;
+    unsigned long long need;               // record capacity that would have sufficed (fullest shard x shards)
+    unsigned long long stats[DCN_N_STATS]; // the six ProcessingStats counters
 };
 
 struct dcn_scan_args {
@@ -139,8 +151,10 @@ struct dcn_scan_args {
 };
 
 // ---- kernels launched by api.hip -------------------------------------------------------------------
-int dcn_launch_pack(const uint8_t *d_ascii, uint64_t n_bases, uint32_t *d_packed, uint32_t *d_invmask,
-                    hipStream_t stream, bool index_side = false);
+// packs bases [base_begin, base_end) of the stream (whole 32-base groups; bytes at or past base_end read as 'A');
+// status (may be null) receives any_newline
+int dcn_launch_pack(const uint8_t *d_ascii, uint64_t base_begin, uint64_t base_end, uint32_t *d_packed,
+                    uint32_t *d_invmask, dcn_status *status, hipStream_t stream, bool index_side = false);
 int dcn_launch_scan(const dcn_scan_args &args, uint32_t max_tiles, bool dump, hipStream_t stream);
 
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);

@@ -7,6 +7,7 @@ struct dcn_plan_args {
     const uint8_t *ascii;
     const uint64_t *offsets;
     const uint32_t *unit_id; // may be null: unit == read
+    uint32_t unit_base;      // subtracted from every unit_id entry (a chunk of a larger batch); 0 otherwise
     uint32_t n_reads, n_units;
     uint32_t k, w;
     uint64_t prefix_length;
@@ -50,7 +51,7 @@ struct dcn_finish_args {
     uint32_t deplete;
     uint8_t *keep;
     uint32_t *hits, *total;
-    unsigned long long *status_stats;
+    dcn_batch_report *report; // counters and the sticky overflow word of the batch this chunk belongs to
     const dcn_status *status;
 };
 

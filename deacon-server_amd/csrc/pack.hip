@@ -46,13 +46,16 @@ __device__ inline uint32_t invalid4(uint32_t x) {
     return m;
 }
 
-// each thread packs 32 bases: two packed words and one mask word
+// each thread packs 32 bases: two packed words and one mask word.  Groups [g_first, g_first + n_chunks) of the
+// stream are packed (a chunk of a larger batch starts at any group); bytes at or past n_bases read as 'A'.
 template <bool ALIGNED, bool INDEX_SIDE>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, uint64_t n_bases,
                                                    uint32_t *__restrict__ packed,
-                                                   uint32_t *__restrict__ invmask, uint64_t n_chunks) {
+                                                   uint32_t *__restrict__ invmask, uint64_t g_first, uint64_t n_chunks,
+                                                   dcn_status *status) {
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_chunks; t += stride) {
+    uint32_t nl = 0;
+    for (uint64_t t = g_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < g_first + n_chunks; t += stride) {
         uint64_t base = t * 32;
         uint32_t w[8];
         if (ALIGNED && base + 32 <= n_bases) {
@@ -75,6 +78,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
             }
         }
         uint32_t p0 = 0, p1 = 0, m = 0;
+        if (!INDEX_SIDE) {
+            // any '\n' byte in the batch?  (x ^ 0x0A..) has a zero byte <=> some byte of x is '\n'
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t z = w[q] ^ 0x0A0A0A0Au;
+                nl |= (z - 0x01010101u) & ~z & 0x80808080u;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             p0 |= (INDEX_SIDE ? pack4_index_side(w[q]) : pack4(w[q])) << (8 * q);
@@ -86,19 +97,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         packed[2 * t + 1] = p1;
         invmask[t] = m;
     }
+    if (!INDEX_SIDE && nl && status) status->any_newline = 1; // rare; plan_kernel then probes the read ends
 }
 
 } // namespace
 
-int dcn_launch_pack(const uint8_t *d_ascii, uint64_t n_bases, uint32_t *d_packed, uint32_t *d_invmask,
-                    hipStream_t stream, bool index_side) {
-    uint64_t n_chunks = (n_bases + 31) / 32;
-    if (n_chunks == 0) return DCN_OK;
+int dcn_launch_pack(const uint8_t *d_ascii, uint64_t base_begin, uint64_t base_end, uint32_t *d_packed,
+                    uint32_t *d_invmask, dcn_status *status, hipStream_t stream, bool index_side) {
+    if (base_end <= base_begin) return DCN_OK;
+    const uint64_t g_first = base_begin / 32, n_bases = base_end;
+    uint64_t n_chunks = (base_end + 31) / 32 - g_first;
     uint32_t blocks = (uint32_t)((n_chunks + 255) / 256);
     if (blocks > 256 * 32) blocks = 256 * 32;
     bool aligned = (reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0;
 #define DCN_PACK(AL, IX) \
-    hipLaunchKernelGGL((pack_kernel<AL, IX>), dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed, d_invmask, n_chunks)
+    hipLaunchKernelGGL((pack_kernel<AL, IX>), dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed, d_invmask, g_first, n_chunks, status)
     if (index_side) {
         if (aligned) DCN_PACK(true, true);
         else DCN_PACK(false, true);

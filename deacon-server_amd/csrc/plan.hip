@@ -11,7 +11,7 @@ __device__ inline uint32_t effective_windows(const uint8_t *ascii, uint64_t off,
                                              uint32_t k, uint32_t l) {
     if (len < k) return 0;                      // :217 -- tested on the full read, before the prefix cut
     uint64_t n = (prefix > 0 && len > prefix) ? prefix : len; // :222-226
-    if (n > 0 && ascii[off + n - 1] == '\n') n -= 1;          // :229
+    if (ascii && n > 0 && ascii[off + n - 1] == '\n') n -= 1; // :229 (ascii == null: no read of the batch ends in one)
     return n >= l ? (uint32_t)(n - l + 1) : 0;
 }
 
@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     const uint32_t block_first = blockIdx.x * PLAN_READS;
     const uint32_t block_end = min(a.n_reads, block_first + PLAN_READS);
     if (tid == 0) n_long = 0;
+    // the one-byte probe for a trailing '\n' costs a 64-byte sector per read: skipped when the batch came packed
+    // (a.ascii == null) or when the pack kernel, which reads every byte anyway, saw no '\n' at all
+    const uint8_t *ascii = (a.ascii && a.status->any_newline) ? a.ascii : nullptr;
     uint32_t nwin[PLAN_CH], nt[PLAN_CH], loc[PLAN_CH];
     uint32_t carry = 0; // tiles of the chunks before this one
 #pragma unroll
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
         nt[c] = 0;
         if (r < a.n_reads) {
             uint64_t off = a.offsets[r];
-            nwin[c] = effective_windows(a.ascii, off, a.offsets[r + 1] - off, a.prefix_length, a.k, a.k + a.w - 1);
+            nwin[c] = effective_windows(ascii, off, a.offsets[r + 1] - off, a.prefix_length, a.k, a.k + a.w - 1);
             nt[c] = (nwin[c] + a.tile_windows - 1) / a.tile_windows;
         }
         uint32_t inc = nt[c];
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
         uint32_t u = r;
         bool unit_head = true;
         if (a.unit_id) {
-            u = a.unit_id[r];
-            unit_head = r == 0 || a.unit_id[r - 1] != u;
+            u = a.unit_id[r] - a.unit_base;
+            unit_head = r == 0 || a.unit_id[r - 1] != a.unit_id[r];
             if (unit_head) a.unit_first_read[u] = r;
             if (r == a.n_reads - 1) a.unit_first_read[a.n_units] = a.n_reads;
         }
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
             if (a.unit_id) {
                 // the unit's other reads follow; they are contiguous in tile space only inside this workgroup
                 uint32_t q = r + 1;
-                while (q < a.n_reads && a.unit_id[q] == u) {
+                while (q < a.n_reads && a.unit_id[q] - a.unit_base == u) {
                     if (q >= block_end) {
                         count = 0xFFFFFFFFu;
                         break;
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     for (uint32_t q = 0; q < n_long; ++q) {
         const uint32_t li = long_reads[q], lr = block_first + li;
         const uint32_t lnt = s_tiles[li], lfirst = s_first[li];
-        const uint32_t lu = a.unit_id ? a.unit_id[lr] : lr;
+        const uint32_t lu = a.unit_id ? a.unit_id[lr] - a.unit_base : lr;
         const uint64_t loff = a.offsets[lr];
-        const uint32_t lnwin = effective_windows(a.ascii, loff, a.offsets[lr + 1] - loff, a.prefix_length, a.k, a.k + a.w - 1);
+        const uint32_t lnwin = effective_windows(ascii, loff, a.offsets[lr + 1] - loff, a.prefix_length, a.k, a.k + a.w - 1);
         for (uint32_t j = OWN + tid; j < lnt; j += blockDim.x) write_tile(a, lfirst, j, loff, lnwin, lu);
     }
 }
@@ -260,7 +263,21 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
             }
         }
     }
-    if (!a.offsets || a.status->rec_overflow) return; // an overflowed attempt is re-run: do not count it
+    if (a.status->rec_overflow) {
+        // sticky: the status words are cleared before the next chunk, the report is read when the batch is waited for
+        if (blockIdx.x == 0 && threadIdx.x < 64) {
+            unsigned long long need = 0;
+            for (uint32_t sidx = threadIdx.x; sidx < DCN_REC_SHARDS; sidx += 64) need = max(need, a.status->rec_count[sidx]);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) need = max(need, (unsigned long long)__shfl_xor((long long)need, d, 64));
+            if (threadIdx.x == 0) {
+                a.report->overflow = 1;
+                atomicMax(&a.report->need, need * DCN_REC_SHARDS);
+            }
+        }
+        return; // an overflowed attempt is re-run: do not count it
+    }
+    if (!a.offsets) return;
     __shared__ unsigned long long red[DCN_N_STATS][4];
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
     __syncthreads();
     if (threadIdx.x < DCN_N_STATS) {
         unsigned long long v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-        if (v) atomicAdd(&a.status_stats[threadIdx.x], v);
+        if (v) atomicAdd(&a.report->stats[threadIdx.x], v);
     }
 }
 

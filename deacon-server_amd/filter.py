@@ -48,6 +48,33 @@ def concat_reads(reads):
     return bases, offsets
 
 
+def pack_ascii(bases):
+    """Concatenated ASCII -> (packed u32[2*ceil(n/32)], invmask u32[ceil(n/32)]) in the layout
+    dcn_filter_batch_packed takes (PackedSeqVec::from_ascii + the mask loop, filter_common.rs:238-258)."""
+    bases = _as_u8(bases)
+    g = (len(bases) + 31) // 32
+    packed = np.zeros(max(2 * g, 1), np.uint32)
+    mask = np.zeros(max(g, 1), np.uint32)
+    N.check(N.lib().dcn_pack_ascii(_ptr(bases) if len(bases) else None, len(bases), _ptr(packed), _ptr(mask)))
+    return packed[:2 * g], mask[:g]
+
+
+class PendingBatch:
+    """A batch in flight (dcn_filter_batch_submit): holds the arrays the library reads and writes until wait()."""
+
+    def __init__(self, proc, ticket, n_units, keep, hits, total, inputs):
+        self.proc, self.ticket, self.n_units = proc, ticket, n_units
+        self.keep, self.hits, self.total, self._inputs = keep, hits, total, inputs
+
+    def wait(self):
+        N.check(N.lib().dcn_filter_batch_wait(self.proc._h, self.ticket))
+        self._inputs = None
+        keep = self.keep[:self.n_units].astype(bool)
+        if self.hits is None:
+            return keep
+        return keep, self.hits[:self.n_units], self.total[:self.n_units]
+
+
 class PinnedBuffer:
     """Page-locked host memory from dcn_host_alloc, viewed as a numpy array: batches built in one go over PCIe
     without the staging copy.  Keep the object alive while `.array` is in use."""
@@ -113,6 +140,12 @@ class Index:
         h = C.c_void_p()
         N.check(N.lib().dcn_index_union(arr, len(indexes), C.byref(h)))
         return cls(h, indexes[0].device)
+
+    def clone(self, device):
+        """Replica on another (or the same) device, copied device to device (dcn_index_clone)."""
+        h = C.c_void_p()
+        N.check(N.lib().dcn_index_clone(self._h, int(device), C.byref(h)))
+        return type(self)(h, int(device))
 
     def diff(self, other):
         """index::diff (index.rs:421-536): the minimizers of self that are not in other."""
@@ -202,6 +235,54 @@ class FilterProcessor:
         N.check(N.lib().dcn_filter_batch(self._h, _ptr(bases) if len(bases) else None, _ptr(offsets),
                                          _ptr(unit_id), n_reads, C.byref(p), _ptr(keep), _ptr(hits), _ptr(total)))
         return keep[:n_units].astype(bool), hits[:n_units], total[:n_units]
+
+    def _outputs(self, offsets, unit_id, counts, out):
+        n_reads = len(offsets) - 1
+        n_units = (int(unit_id[-1]) + 1 if n_reads else 0) if unit_id is not None else n_reads
+        if out is not None:
+            keep, hits, total = out
+        else:
+            keep = np.zeros(max(n_units, 1), np.uint8)
+            hits = np.zeros(max(n_units, 1), np.uint32) if counts else None
+            total = np.zeros(max(n_units, 1), np.uint32) if counts else None
+        return n_reads, n_units, keep, hits, total
+
+    def submit(self, bases, offsets, unit_id=None, counts=True, out=None):
+        """dcn_filter_batch_submit: returns a PendingBatch; up to two may be in flight per processor.
+        out = (keep u8[], hits u32[] | None, total u32[] | None) lets the caller supply (page-locked) result arrays."""
+        bases = _as_u8(bases)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if unit_id is not None:
+            unit_id = np.ascontiguousarray(unit_id, dtype=np.uint32)
+        n_reads, n_units, keep, hits, total = self._outputs(offsets, unit_id, counts, out)
+        p = self._params()
+        t = C.c_uint64()
+        N.check(N.lib().dcn_filter_batch_submit(self._h, _ptr(bases) if len(bases) else None, _ptr(offsets),
+                                                _ptr(unit_id), n_reads, C.byref(p), _ptr(keep), _ptr(hits),
+                                                _ptr(total), C.byref(t)))
+        return PendingBatch(self, t.value, n_units, keep, hits, total, (bases, offsets, unit_id, p))
+
+    def submit_packed(self, packed, invmask, offsets, unit_id=None, counts=True, out=None):
+        """dcn_filter_batch_packed_submit: the batch as a 2-bit stream + invalid mask (see pack_ascii)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint32)
+        invmask = np.ascontiguousarray(invmask, dtype=np.uint32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if unit_id is not None:
+            unit_id = np.ascontiguousarray(unit_id, dtype=np.uint32)
+        n_reads, n_units, keep, hits, total = self._outputs(offsets, unit_id, counts, out)
+        g = (int(offsets[-1]) + 31) // 32 if n_reads else 0
+        if len(packed) < 2 * g or len(invmask) < g:
+            raise ValueError("packed / invmask must hold whole 32-base groups of the batch")
+        p = self._params()
+        t = C.c_uint64()
+        N.check(N.lib().dcn_filter_batch_packed_submit(self._h, _ptr(packed), _ptr(invmask), _ptr(offsets),
+                                                       _ptr(unit_id), n_reads, C.byref(p), _ptr(keep), _ptr(hits),
+                                                       _ptr(total), C.byref(t)))
+        return PendingBatch(self, t.value, n_units, keep, hits, total, (packed, invmask, offsets, unit_id, p))
+
+    def filter_batch_packed(self, packed, invmask, offsets, unit_id=None, counts=True):
+        """dcn_filter_batch_packed (blocking)."""
+        return self.submit_packed(packed, invmask, offsets, unit_id, counts).wait()
 
     def filter_reads(self, reads, paired=False):
         """reads: list of sequences; paired=True: reads 2i and 2i+1 are the mates of pair i."""
@@ -317,6 +398,14 @@ class FilterProcessor:
             self.close()
         except Exception:
             pass
+
+
+def stats_allreduce(processors):
+    """dcn_stats_allreduce: the six counters summed over several processors of this process."""
+    arr = (C.c_void_p * len(processors))(*[p._h for p in processors])
+    c = (C.c_uint64 * N.N_STATS)()
+    N.check(N.lib().dcn_stats_allreduce(arr, len(processors), c))
+    return dict(zip(N.STAT_NAMES, (int(x) for x in c)))
 
 
 def get_minimizer_hashes_and_positions(processor, seq, prefix_length=0):

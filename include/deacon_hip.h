@@ -113,6 +113,11 @@ int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n,
 int dcn_index_contains_device(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
                               void *stream);
 
+/* Replica of an index on another (or the same) device, copied device to device (hipMemcpyPeer over xGMI): the
+ * reference shares ONE set between its workers through an Arc (src/local_filter.rs:630-631); a multi-GPU host
+ * loads or builds the index once and clones it to every other device instead of repeating the host-to-device copy. */
+int dcn_index_clone(const dcn_index *index, int device, dcn_index **out);
+
 void dcn_index_destroy(dcn_index *index);
 
 /* ---- context -------------------------------------------------------------------------------------- */
@@ -141,10 +146,54 @@ void dcn_ctx_destroy(dcn_ctx *ctx);
  * outside --debug (src/local_filter.rs:350-371): the kernels may then stop probing a unit as soon as its
  * decision is fixed (abs_threshold distinct hits reached while the relative threshold cannot ask for more).
  * keep and the six counters are identical in both forms.
- * Blocking; internally pinned staging + hipMemcpyAsync on a side stream overlapped with the kernels. */
+ *
+ * Blocking (= dcn_filter_batch_submit + dcn_filter_batch_wait).  Inside, the batch is cut at unit boundaries into
+ * chunks of ~32 Mbp: chunk i's kernels run while chunk i+1 crosses PCIe on a side stream and chunk i-1's results
+ * travel back on a third.  What crosses the link depends on where `bases` lives:
+ *   page-locked memory (dcn_host_alloc / hipHostRegister)  the ASCII is DMA'd as it is and packed on the device;
+ *   pageable memory   host threads pack it to 2 bits + 1 mask bit per base straight into the context's pinned
+ *                     staging ring (0.375 instead of 1 byte per base on the link -- the reference packs on the host
+ *                     too: src/filter_common.rs:238-258).
+ * A batch that needed more hit-record scratch than the context has is re-run after growing it: callers never see
+ * DCN_ERR_CAPACITY for that. */
 int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
                      uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
                      uint32_t *total);
+
+/* Asynchronous form: the paraseq workers of the reference overlap reading, filtering and writing across threads
+ * (src/local_filter.rs:696-709); here ONE caller thread keeps up to two batches in flight per context.
+ * submit validates the batch, enqueues its copies and kernels and returns a ticket; wait(ticket) blocks until the
+ * batch is done, delivers keep/hits/total and adds the batch's six counters to the context's.  All input and
+ * output arrays must stay valid and unmodified until wait returns.  A third submit without a wait fails with
+ * DCN_ERR_CAPACITY.  Tickets may be waited for in any order. */
+int dcn_filter_batch_submit(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
+                            uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
+                            uint32_t *total, uint64_t *ticket);
+int dcn_filter_batch_wait(dcn_ctx *ctx, uint64_t ticket);
+
+/* The same batch handed over already packed, as the reference holds it after PackedSeqVec::from_ascii and its mask
+ * loop (src/filter_common.rs:238-258) -- for the concatenated batch instead of one read at a time:
+ *   packed   2 bits per base, code (c >> 1) & 3 of the ASCII byte (A=0 C=1 T=2 G=3, non-ACGT mapped the same
+ *            lossy way); base i of the batch = bits [2(i%16), +2) of packed[i/16], i.e. bits 2(i%4) of byte i/4:
+ *            packed-seq's own byte order
+ *   invmask  1 bit per base, bit i%32 of invmask[i/32] set iff byte i is not one of ACGTacgt
+ *   offsets / unit_id / outputs as for dcn_filter_batch (offsets are BASE indices into the stream)
+ * Both arrays must be allocated in whole 32-base groups: 2 * ceil(n_bases/32) and ceil(n_bases/32) words
+ * (dcn_pack_ascii fills them).  Reads must not end in '
+' (src/filter_common.rs:229 strips one from the ASCII;
+ * a packed stream cannot show it).  The pack kernel is skipped; 0.375 bytes per base cross the link. */
+int dcn_filter_batch_packed(dcn_ctx *ctx, const uint32_t *packed, const uint32_t *invmask, const uint64_t *offsets,
+                            const uint32_t *unit_id, uint32_t n_reads, const dcn_params *params, uint8_t *keep,
+                            uint32_t *hits, uint32_t *total);
+int dcn_filter_batch_packed_submit(dcn_ctx *ctx, const uint32_t *packed, const uint32_t *invmask,
+                                   const uint64_t *offsets, const uint32_t *unit_id, uint32_t n_reads,
+                                   const dcn_params *params, uint8_t *keep, uint32_t *hits, uint32_t *total,
+                                   uint64_t *ticket);
+
+/* Host-side packer producing exactly that layout from concatenated ASCII (AVX2 + BMI2 where the CPU has them,
+ * split over the library's host threads, DCN_HOST_THREADS).  Input formatting only: nothing here hashes or
+ * decides.  packed / invmask: 2 * ceil(n_bases/32) and ceil(n_bases/32) u32 words. */
+int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uint32_t *invmask);
 
 /* Same computation on inputs already resident in device memory (all pointers are DEVICE pointers on the
  * context's GPU; d_unit_id / d_hits / d_total may be NULL).  n_bases = offsets[n_reads], n_units = number
@@ -154,9 +203,10 @@ int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, const uint64_t
                             const uint32_t *d_unit_id, uint32_t n_reads, uint64_t n_bases, uint32_t n_units,
                             const dcn_params *params, uint8_t *d_keep, uint32_t *d_hits, uint32_t *d_total);
 
-/* Wait for everything enqueued on the context; reports deferred errors of the device pipeline
- * (e.g. DCN_ERR_CAPACITY when a scratch buffer overflowed; the batch must then be re-submitted after
- * dcn_ctx_reserve_records()). */
+/* Wait for everything enqueued on the context by dcn_filter_batch_device; reports deferred errors of the device
+ * pipeline.  DCN_ERR_CAPACITY: the hit-record scratch overflowed in SOME batch enqueued since the previous
+ * synchronize (the flag is sticky across batches); results and counters of all of them are then unspecified:
+ * dcn_ctx_reserve_records(), dcn_ctx_reset_stats() and enqueue them again. */
 int dcn_ctx_synchronize(dcn_ctx *ctx);
 
 /* Grow the scratch that holds (unit, hash) hit records of units spanning several tiles (long reads). */
@@ -192,6 +242,11 @@ int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, const uint64_t 
 /* Counters accumulated on the device over every dcn_filter_batch* call since the last reset. */
 int dcn_ctx_stats(dcn_ctx *ctx, uint64_t counters[DCN_N_STATS]);
 int dcn_ctx_reset_stats(dcn_ctx *ctx);
+
+/* Sum of the six counters over n_ctx contexts of THIS process (several devices, or several contexts per device):
+ * the merge of the per-worker ProcessingStats at src/local_filter.rs:388-396.  In-process contexts share an address
+ * space, so this is a host sum; one-process-per-GPU jobs reduce the same six words with RCCL (bench.py). */
+int dcn_stats_allreduce(dcn_ctx *const *ctxs, int n_ctx, uint64_t counters[DCN_N_STATS]);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 

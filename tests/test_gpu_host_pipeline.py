@@ -1,0 +1,250 @@
+"""GPU parity tests of the pipelined host entry points, all through the C ABI and all against the CPU oracle:
+chunked copy/compute overlap inside dcn_filter_batch, dcn_filter_batch_submit / _wait with two batches in flight,
+2-bit packed input (dcn_filter_batch_packed, dcn_pack_ascii), the sticky record-overflow word of the
+device-pointer API, and the in-process multi-context pieces (dcn_index_clone, dcn_stats_allreduce)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import random_reads
+from test_gpu_parity import make_index_pair, sample_reads
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def genome():
+    return random_reads(np.random.default_rng(101), 1, 150_000, 150_000)[0]
+
+
+@pytest.fixture(scope="module")
+def index_pair(oracle, dcn, genome):
+    return make_index_pair(oracle, dcn, [genome])
+
+
+def small_chunks(monkeypatch, n=20_000):
+    """contexts created afterwards cut host batches every ~n bases"""
+    monkeypatch.setenv("DCN_CHUNK_BASES", str(n))
+
+
+def mixed_reads(rng, genome, n_short=3000, n_long=12):
+    reads = sample_reads(rng, genome, n_short, 30, 400)
+    for _ in range(n_long):  # long reads straddle many chunks' worth of tiles
+        ln = int(rng.integers(5_000, 60_000))
+        s = int(rng.integers(0, len(genome) - ln))
+        reads.insert(int(rng.integers(0, len(reads))), genome[s:s + ln])
+    reads.insert(7, b"")
+    reads.insert(8, b"ACGT")
+    return reads
+
+
+def oracle_batch(oracle, oidx, proc, b, o, uid):
+    return oracle.filter_batch(oidx, b, o, uid, abs_threshold=proc.abs_threshold, rel_threshold=proc.rel_threshold,
+                               prefix_length=proc.prefix_length, deplete=proc.deplete, threads=4)
+
+
+def assert_same(got, want):
+    assert got[2].tolist() == want[2].tolist(), "total minimizers differ"
+    assert got[1].tolist() == want[1].tolist(), "distinct hit counts differ"
+    assert got[0].tolist() == want[0].tolist(), "keep decisions differ"
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("paired", [False, True])
+def test_chunked_batch_matches_oracle(oracle, dcn, genome, index_pair, monkeypatch, pinned, paired):
+    """a batch cut into dozens of chunks (pageable: host-packed into the staging ring; page-locked: ASCII DMA +
+    device pack) gives the oracle's results, chunk seams inside and between units included"""
+    small_chunks(monkeypatch)
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(102 + pinned + 2 * paired)
+    reads = mixed_reads(rng, genome)
+    b, o = oracle.concat_reads(reads)
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32) if paired else None
+    proc = dcn.FilterProcessor(gidx, deplete=paired, max_batch_bases=len(b) + 100, max_batch_reads=len(reads) + 8)
+    want = oracle_batch(oracle, oidx, proc, b, o, uid)
+    if pinned:
+        pb, po = dcn.PinnedBuffer(len(b), np.uint8), dcn.PinnedBuffer(len(o), np.uint64)
+        pb.array[:], po.array[:] = b, o
+        got = proc.filter_batch(pb.array, po.array, uid)
+    else:
+        got = proc.filter_batch(b, o, uid)
+    assert_same(got, want)
+    s = proc.stats()
+    assert s["total_seqs"] == len(reads) and s["total_bp"] == len(b)
+    assert len(reads) % 2 == 0
+    assert s["output_seq_counter"] == (2 if paired else 1) * int(want[0].sum())
+    # decisions only, same chunks
+    assert proc.filter_batch(b, o, uid, counts=False).tolist() == want[0].tolist()
+    proc.close()
+
+
+def test_submit_wait_two_in_flight(oracle, dcn, genome, index_pair, monkeypatch):
+    small_chunks(monkeypatch, 50_000)
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(110)
+    batches = []
+    for i in range(5):
+        reads = sample_reads(rng, genome, 1500 + 200 * i, 40, 300)
+        b, o = oracle.concat_reads(reads)
+        uid = (np.arange(len(reads)) // 2).astype(np.uint32) if i % 2 else None
+        batches.append((b, o, uid))
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 20, max_batch_reads=1 << 12)
+    wants = [oracle_batch(oracle, oidx, proc, *x) for x in batches]
+    pending = [proc.submit(*batches[0]), proc.submit(*batches[1])]
+    with pytest.raises(dcn.DeaconHipError) as e:  # a third one without a wait
+        proc.submit(*batches[2])
+    assert e.value.code == dcn._native.DCN_ERR_CAPACITY
+    with pytest.raises(dcn.DeaconHipError):  # the device-pointer API and the dump seam refuse while batches fly
+        proc.minimizer_hashes_batch(batches[0][0], batches[0][1])
+    results = []
+    for nxt in (2, 3, 4):
+        results.append(pending.pop(0).wait())
+        pending.append(proc.submit(*batches[nxt], counts=nxt != 3))
+    # out-of-order wait of the last two
+    last = pending[1].wait()
+    results.append(pending[0].wait())
+    results.append(last)
+    for i, (got, want) in enumerate(zip(results, wants)):
+        if i == 3:
+            assert got.tolist() == want[0].tolist()
+        else:
+            assert_same(got, want)
+    s = proc.stats()
+    assert s["total_seqs"] == sum(len(x[1]) - 1 for x in batches)
+    assert s["total_bp"] == sum(len(x[0]) for x in batches)
+    with pytest.raises(dcn.DeaconHipError):
+        dcn._native.check(dcn._native.lib().dcn_filter_batch_wait(proc._h, 12345))
+    proc.close()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_packed_input(oracle, dcn, genome, index_pair, monkeypatch, paired):
+    """dcn_filter_batch_packed on the stream dcn_pack_ascii produces == the oracle on the ASCII"""
+    small_chunks(monkeypatch, 30_000)
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(120 + paired)
+    reads = mixed_reads(rng, genome, 2500, 6)
+    reads += random_reads(rng, 200, 60, 200, p_n=0.02, p_lower=0.3, alphabet=b"ACGTNRYKM")
+    b, o = oracle.concat_reads(reads)
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32) if paired else None
+    packed, mask = dcn.pack_ascii(b)
+    for prefix in (0, 120):
+        proc = dcn.FilterProcessor(gidx, prefix_length=prefix, deplete=not paired, max_batch_bases=len(b) + 64,
+                                   max_batch_reads=len(reads))
+        want = oracle_batch(oracle, oidx, proc, b, o, uid)
+        assert_same(proc.filter_batch_packed(packed, mask, o, uid), want)
+        assert proc.filter_batch_packed(packed, mask, o, uid, counts=False).tolist() == want[0].tolist()
+        # page-locked packed buffers: straight DMA
+        pp, pm = dcn.PinnedBuffer(len(packed), np.uint32), dcn.PinnedBuffer(len(mask), np.uint32)
+        pp.array[:], pm.array[:] = packed, mask
+        assert_same(proc.filter_batch_packed(pp.array, pm.array, o, uid), want)
+        proc.close()
+    with pytest.raises(ValueError):
+        dcn.FilterProcessor(gidx, max_batch_bases=1 << 20, max_batch_reads=1 << 12).filter_batch_packed(
+            packed[:10], mask, o, uid)
+
+
+def test_trailing_newline_reads_through_the_host_packed_path(oracle, dcn, genome, index_pair, monkeypatch):
+    """src/filter_common.rs:229 strips one trailing newline; the host-packed transport cannot see read ends, so a
+    batch holding any newline byte is sent again as ASCII"""
+    small_chunks(monkeypatch, 40_000)
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(130)
+    reads = sample_reads(rng, genome, 1200, 45, 200)
+    for i in range(0, len(reads), 7):
+        reads[i] = reads[i] + b"\n"
+    reads[3] = reads[3][:20] + b"\n" + reads[3][21:]  # one in the middle too: an invalid base, not stripped
+    b, o = oracle.concat_reads(reads)
+    for prefix in (0, 100):
+        proc = dcn.FilterProcessor(gidx, prefix_length=prefix, max_batch_bases=1 << 20, max_batch_reads=1 << 12)
+        want = oracle_batch(oracle, oidx, proc, b, o, None)
+        assert_same(proc.filter_batch(b, o), want)
+        pb = dcn.PinnedBuffer(len(b), np.uint8)
+        pb.array[:] = b
+        assert_same(proc.filter_batch(pb.array, o), want)
+        proc.close()
+
+
+def test_record_overflow_in_a_pipelined_batch_is_rerun(oracle, dcn, genome, index_pair, monkeypatch):
+    """long reads overflow the small default record scratch of a small context in some chunks; wait() grows it and
+    runs the batch again, counters counted once"""
+    small_chunks(monkeypatch, 100_000)
+    oidx, gidx = index_pair
+    reads = [genome[i * 10_000:i * 10_000 + 60_000] for i in range(8)] + [genome[:50_000]] * 2
+    reads += sample_reads(np.random.default_rng(131), genome, 500, 50, 150)
+    b, o = oracle.concat_reads(reads)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=len(b) + 64, max_batch_reads=1 << 10)
+    want = oracle_batch(oracle, oidx, proc, b, o, None)
+    p1 = proc.submit(b, o)
+    p2 = proc.submit(b, o)
+    assert_same(p1.wait(), want)
+    assert_same(p2.wait(), want)
+    s = proc.stats()
+    assert s["total_seqs"] == 2 * len(reads) and s["total_bp"] == 2 * len(b)
+    proc.close()
+
+
+def test_sticky_overflow_of_the_device_pointer_api(oracle, dcn, genome, index_pair):
+    """an overflow in batch N must not be erased by the status clearing of batch N+1"""
+    torch = pytest.importorskip("torch")
+    oidx, gidx = index_pair
+    dev = torch.device("cuda:0")
+    big = [genome[:120_000]] * 6
+    small = [genome[100:250]] * 4
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 20, max_batch_reads=64)
+    bufs = []
+    for reads in (big, small):
+        b, o = oracle.concat_reads(reads)
+        d_b, d_o = torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int64)).to(dev)
+        d_k = torch.zeros(len(reads), dtype=torch.uint8, device=dev)
+        d_h = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+        d_t = torch.zeros(len(reads), dtype=torch.int32, device=dev)
+        bufs.append((reads, b, o, d_b, d_o, d_k, d_h, d_t))
+    torch.cuda.synchronize()
+
+    def enqueue(x):
+        reads, b, o, d_b, d_o, d_k, d_h, d_t = x
+        proc.filter_batch_device(d_b.data_ptr(), d_o.data_ptr(), len(reads), len(b), d_k.data_ptr(), d_h.data_ptr(),
+                                 d_t.data_ptr())
+
+    enqueue(bufs[0])
+    enqueue(bufs[1])
+    with pytest.raises(dcn.DeaconHipError) as e:
+        proc.synchronize()
+    assert e.value.code == dcn._native.DCN_ERR_CAPACITY
+    proc.reserve_records(1 << 20)
+    proc.reset_stats()
+    enqueue(bufs[0])
+    enqueue(bufs[1])
+    proc.synchronize()
+    for reads, b, o, d_b, d_o, d_k, d_h, d_t in bufs:
+        want = oracle.filter_batch(oidx, b, o, None, threads=2)
+        assert d_h.cpu().numpy().tolist() == want[1].tolist()
+        assert d_k.cpu().numpy().astype(bool).tolist() == want[0].tolist()
+    assert proc.stats()["total_seqs"] == len(big) + len(small)
+    proc.close()
+
+
+def test_index_clone_and_stats_allreduce(oracle, dcn, genome, index_pair):
+    oidx, gidx = index_pair
+    clone = gidx.clone(0)  # same device on the 1-GPU box: the device-to-device copy path
+    assert clone.header() == gidx.header()
+    keys = oidx.keys()
+    assert clone.contains(keys).all() and not clone.contains(keys ^ np.uint64(1)).all()
+    rng = np.random.default_rng(140)
+    reads = sample_reads(rng, genome, 2000, 50, 250)
+    b, o = oracle.concat_reads(reads)
+    p1 = dcn.FilterProcessor(gidx, max_batch_bases=1 << 20, max_batch_reads=1 << 12)
+    p2 = dcn.FilterProcessor(clone, max_batch_bases=1 << 20, max_batch_reads=1 << 12)
+    half = 1000
+    a = p1.filter_batch(b[:int(o[half])], o[:half + 1])
+    c = p2.filter_batch(b[int(o[half]):], o[half:] - o[half])
+    want = oracle.filter_batch(oidx, b, o, None, threads=2)
+    assert np.concatenate([a[0], c[0]]).tolist() == want[0].tolist()
+    assert np.concatenate([a[1], c[1]]).tolist() == want[1].tolist()
+    tot = dcn.stats_allreduce([p1, p2])
+    assert tot["total_seqs"] == len(reads) and tot["total_bp"] == len(b)
+    assert tot["output_seq_counter"] == int(want[0].sum())
+    with pytest.raises(dcn.DeaconHipError):
+        gidx.clone(99)

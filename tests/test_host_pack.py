@@ -1,0 +1,42 @@
+"""dcn_pack_ascii (host-side input formatting, no GPU needed): the 2-bit stream and the invalid-base mask it
+writes are PackedSeqVec::from_ascii's code (c >> 1) & 3 and the mask loop of src/filter_common.rs:238-258,
+stated here in numpy, for every byte value, ragged lengths and sizes that take the threaded path."""
+import numpy as np
+import pytest
+
+
+def numpy_pack(b):
+    n = len(b)
+    g = (n + 31) // 32
+    padded = np.full(32 * g, ord("A"), np.uint8)
+    padded[:n] = b
+    codes = ((padded >> 1) & 3).astype(np.uint32).reshape(-1, 16)
+    packed = (codes << (2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+    low = padded | 0x20
+    bad = ~((low == ord("a")) | (low == ord("c")) | (low == ord("g")) | (low == ord("t")))
+    mask = (bad.reshape(-1, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    return packed, mask
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 63, 64, 1000, 4097, 300_001])
+def test_pack_ascii_matches_the_definition(dcn, n):
+    rng = np.random.default_rng(n)
+    b = rng.integers(0, 256, n, dtype=np.uint8)  # every byte value, not only nucleotides
+    if n > 100:
+        b[::3] = np.frombuffer(b"ACGTacgtNn\n", np.uint8)[rng.integers(0, 11, len(b[::3]))]
+    packed, mask = dcn.pack_ascii(b)
+    want_p, want_m = numpy_pack(b)
+    assert packed.tolist() == want_p.tolist()
+    assert mask.tolist() == want_m.tolist()
+
+
+def test_pack_ascii_threaded_path_and_codes(dcn):
+    rng = np.random.default_rng(7)
+    b = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, 6_000_000)]
+    packed, mask = dcn.pack_ascii(b)
+    want_p, want_m = numpy_pack(b)
+    assert np.array_equal(packed, want_p) and np.array_equal(mask, want_m)
+    # A=0 C=1 T=2 G=3
+    p, m = dcn.pack_ascii(b"ACTGacgtN")
+    assert [(int(p[0]) >> (2 * i)) & 3 for i in range(9)] == [0, 1, 2, 3, 0, 1, 3, 2, 3]
+    assert int(m[0]) == 1 << 8

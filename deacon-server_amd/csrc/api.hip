@@ -362,9 +362,11 @@ struct dcn_ctx {
     uint32_t *d_unit_scratch = nullptr; // g_total | g_hitcnt | g_distinct | g_zero, max_reads each
     uint32_t *d_caps = nullptr, *d_set_off = nullptr;
     // hit records + distinct sets
-    uint64_t rec_capacity = 0;
-    uint32_t *d_rec_unit = nullptr;
+    // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
+    // units whose hits do not fit the LDS set of the distinct pass (4 slots per record of capacity)
     uint64_t *d_rec_hash = nullptr;
+    uint32_t *d_tile_hits = nullptr;
+    uint64_t rec_capacity = 0;
     uint64_t *d_set_slots = nullptr;
     dcn_status *d_status = nullptr;
     dcn_batch_report *d_report = nullptr; // device-pointer API: counters + sticky overflow since the last synchronize
@@ -413,17 +415,11 @@ uint64_t packed_words(uint64_t max_bases) { return DCN_FRONT_PAD + 2 * ((max_bas
 uint64_t mask_words(uint64_t max_bases) { return DCN_FRONT_PAD + (max_bases + 31) / 32 + DCN_TAIL_PAD; }
 
 int alloc_records(dcn_ctx *c, uint64_t n_records) {
-    n_records = (n_records + DCN_REC_SHARDS - 1) / DCN_REC_SHARDS * DCN_REC_SHARDS;
-    if (n_records > (1ull << 29)) return dcn_fail(DCN_ERR_CAPACITY, "more than 2^29 hit records per batch: use smaller batches");
-    if (c->d_rec_unit) hipFree(c->d_rec_unit);
-    if (c->d_rec_hash) hipFree(c->d_rec_hash);
+    n_records = (n_records + 63) / 64 * 64;
+    if (n_records > (1ull << 29)) return dcn_fail(DCN_ERR_CAPACITY, "more than 2^29 hit records in global sets per batch: use smaller batches");
     if (c->d_set_slots) hipFree(c->d_set_slots);
-    c->d_rec_unit = nullptr;
-    c->d_rec_hash = nullptr;
     c->d_set_slots = nullptr;
     c->rec_capacity = 0;
-    DCN_TRY(dev_alloc(&c->d_rec_unit, n_records, "rec_unit"));
-    DCN_TRY(dev_alloc(&c->d_rec_hash, n_records, "rec_hash"));
     DCN_TRY(dev_alloc(&c->d_set_slots, 4 * n_records + 64, "set_slots"));
     c->rec_capacity = n_records;
     return DCN_OK;
@@ -453,7 +449,7 @@ void free_ctx(dcn_ctx *c) {
     void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask,
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
                    c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
-                   c->d_set_off, c->d_rec_unit, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
+                   c->d_set_off, c->d_tile_hits, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
     for (void *p : dev)
         if (p) hipFree(p);
@@ -608,9 +604,9 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     sa.unit_state = c->d_unit_state;
     sa.g_total = g_total;
     sa.g_hitcnt = g_hitcnt;
-    sa.rec_unit = c->d_rec_unit;
+    sa.g_zero = g_zero;
     sa.rec_hash = c->d_rec_hash;
-    sa.rec_capacity = c->rec_capacity;
+    sa.tile_hits = c->d_tile_hits;
     sa.status = c->d_status;
     uint64_t tile_bound = (uint64_t)n_reads + (v.b1 - v.b0) / c->tile_windows + 1;
     if (tile_bound > c->max_tiles) tile_bound = c->max_tiles;
@@ -618,12 +614,15 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     DCN_PROF_MARK(DCN_STAGE_SCAN);
 
     dcn_distinct_args da;
-    da.rec_unit = c->d_rec_unit;
+    da.tiles = c->d_tiles;
+    da.n_tiles = &c->d_status->n_tiles;
+    da.unit_tile_first = c->d_unit_tile_first;
+    da.unit_tile_count = c->d_unit_tile_count;
+    da.unit_state = c->d_unit_state;
+    da.tile_hits = c->d_tile_hits;
     da.rec_hash = c->d_rec_hash;
-    da.rec_capacity = c->rec_capacity;
     da.g_hitcnt = g_hitcnt;
     da.g_distinct = g_distinct;
-    da.g_zero = g_zero;
     da.set_off = c->d_set_off;
     da.set_slots = c->d_set_slots;
     da.set_capacity = 4 * c->rec_capacity + 64;
@@ -640,6 +639,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     fa.unit_state = c->d_unit_state;
     fa.g_total = g_total;
     fa.g_distinct = g_distinct;
+    fa.g_zero = g_zero;
     fa.abs_threshold = params->abs_threshold;
     fa.rel_threshold = params->rel_threshold;
     fa.deplete = params->deplete;
@@ -991,13 +991,16 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_unit_scratch, MR * 4, "unit_scratch");
     A(d_caps, MR, "caps");
     A(d_set_off, MR + 1, "set_off");
+    A(d_tile_hits, mt, "tile_hits");
+    A(d_rec_hash, max_batch_bases + 64, "rec_hash");
     A(d_status, 1, "status");
     A(d_report, 1, "report");
 #undef A
-    // hit records: sized for the expected long-read density (1 minimizer per 8 windows, half of them hits),
-    // grown on demand by the host API / dcn_ctx_reserve_records
-    if ((rc = alloc_records(c, std::min<uint64_t>(std::max<uint64_t>(max_batch_bases / 16, 1u << 16), 1ull << 29))) != DCN_OK)
-        return fail(rc);
+    // global sets of the distinct pass (only units with more hits than its LDS set holds use them): sized for the
+    // expected long-read density, grown on demand by the host API / dcn_ctx_reserve_records
+    uint64_t recs = std::min<uint64_t>(std::max<uint64_t>(max_batch_bases / 16, 1u << 16), 1ull << 29);
+    if (const char *rc_env = getenv("DCN_RECORD_CAPACITY")) recs = std::min<uint64_t>(std::max<uint64_t>(strtoull(rc_env, nullptr, 10), 64), 1ull << 29); // tests: force the growth path
+    if ((rc = alloc_records(c, recs)) != DCN_OK) return fail(rc);
     c->stage_bytes = std::min<uint64_t>(std::max<uint64_t>(max_batch_bases + 64, 4096), 32ull << 20);
     for (int i = 0; i < dcn_ctx::N_STAGE; ++i)
         if (hipHostMalloc((void **)&c->h_stage[i], c->stage_bytes, hipHostMallocDefault) != hipSuccess)
@@ -1665,6 +1668,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
     if (n_hashes > 0 && !hashes) return dcn_fail(DCN_ERR_ARG, "hashes is NULL");
     dcn_ctx *c = ctx;
     DCN_HIP(hipSetDevice(c->device));
+    // a unit with more hashes than the LDS set of the distinct pass holds takes a global set of <= 4 slots per hash
     if (n_hashes > c->rec_capacity) DCN_TRY(dcn_ctx_reserve_records(c, std::min<uint64_t>(n_hashes, 1ull << 29)));
     if (n_hashes > c->rec_capacity) return dcn_fail(DCN_ERR_CAPACITY, "too many hashes in one call");
     uint64_t *d_hashes = nullptr, *d_hoff = nullptr;
@@ -1679,8 +1683,6 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         DCN_HIP(hipMemcpyAsync(d_hashes, hashes, n_hashes * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         DCN_HIP(hipMemcpyAsync(d_hoff, hash_offsets, ((uint64_t)n_units + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         DCN_HIP(hipMemsetAsync(c->d_status, 0, sizeof(dcn_status), st));
-        DCN_HIP(hipMemsetAsync(c->d_unit_state, 0, n_units, st));
-        DCN_HIP(hipMemsetAsync(c->d_unit_scratch, 0, (uint64_t)c->max_reads * 4 * sizeof(uint32_t), st));
         uint32_t *g_total = c->d_unit_scratch, *g_hitcnt = g_total + c->max_reads,
                  *g_distinct = g_hitcnt + c->max_reads, *g_zero = g_distinct + c->max_reads;
         dcn_probe_hashes_args pa;
@@ -1689,27 +1691,35 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         pa.hash_offsets = d_hoff;
         pa.n_hashes = n_hashes;
         pa.n_units = n_units;
+        pa.tiles = c->d_tiles;
+        pa.n_tiles = &c->d_status->n_tiles;
+        pa.tile_hits = c->d_tile_hits;
+        pa.unit_tile_first = c->d_unit_tile_first;
+        pa.unit_tile_count = c->d_unit_tile_count;
+        pa.unit_state = c->d_unit_state;
         pa.g_total = g_total;
         pa.g_hitcnt = g_hitcnt;
-        pa.rec_unit = c->d_rec_unit;
-        pa.rec_hash = c->d_rec_hash;
-        pa.rec_capacity = c->rec_capacity;
+        pa.g_distinct = g_distinct;
+        pa.g_zero = g_zero;
         pa.status = c->d_status;
         DCN_TRY(dcn_launch_probe_hashes(pa, st));
         dcn_distinct_args da;
-        da.rec_unit = c->d_rec_unit;
-        da.rec_hash = c->d_rec_hash;
-        da.rec_capacity = c->rec_capacity;
+        da.tiles = c->d_tiles;
+        da.n_tiles = &c->d_status->n_tiles;
+        da.unit_tile_first = c->d_unit_tile_first;
+        da.unit_tile_count = c->d_unit_tile_count;
+        da.unit_state = c->d_unit_state;
+        da.tile_hits = c->d_tile_hits;
+        da.rec_hash = d_hashes;
         da.g_hitcnt = g_hitcnt;
         da.g_distinct = g_distinct;
-        da.g_zero = g_zero;
         da.set_off = c->d_set_off;
         da.set_slots = c->d_set_slots;
         da.set_capacity = 4 * c->rec_capacity + 64;
         da.n_units = n_units;
         da.status = c->d_status;
         da.caps = c->d_caps;
-    DCN_TRY(dcn_launch_distinct(da, st));
+        DCN_TRY(dcn_launch_distinct(da, st));
         dcn_finish_args fa;
         fa.n_units = n_units;
         fa.unit_first_read = nullptr;
@@ -1717,6 +1727,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         fa.unit_state = c->d_unit_state;
         fa.g_total = g_total;
         fa.g_distinct = g_distinct;
+        fa.g_zero = g_zero;
         fa.abs_threshold = params->abs_threshold;
         fa.rel_threshold = params->rel_threshold;
         fa.deplete = params->deplete;

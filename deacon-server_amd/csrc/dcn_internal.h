@@ -89,18 +89,15 @@ struct dcn_tile {
     uint32_t flags;      // bit0: has carry window (first scanned window only seeds the dedup state)
 };
 
-// The (unit, hash) hit-record buffer is split into DCN_REC_SHARDS equal segments, each with its own append
-// counter (workgroup b appends to shard b % DCN_REC_SHARDS): one global word takes only ~88 atomics/us.
-constexpr uint32_t DCN_REC_SHARDS = 64;
-
 // status words written by the device pipeline (one per ctx, zeroed before every enqueued batch / chunk)
 struct dcn_status {
-    unsigned long long rec_count[DCN_REC_SHARDS]; // hit records appended per shard (may exceed the segment size)
-    uint32_t rec_overflow;                        // records dropped: a segment of the record buffer was too small
+    uint32_t rec_overflow;         // the global hash sets of the distinct pass did not fit their scratch
     uint32_t n_tiles;
-    uint32_t any_records;                         // some kernel appended a hit record: the distinct pass has work
-    uint32_t any_newline;                         // the pack kernel saw a '\n' byte: only then does planning probe read ends
-    unsigned long long set_cursor;                // distinct pass: slots handed out to the per-unit hash sets
+    uint32_t any_records;          // the scan wrote a hit into some tile's run: the distinct pass has work
+    uint32_t any_big;              // some unit has more hits than the LDS set holds: the global-set kernels have work
+    uint32_t any_newline;          // the pack kernel saw a '\n' byte: only then does planning probe read ends
+    uint32_t reserved;
+    unsigned long long set_cursor; // distinct pass: slots handed out to the global per-unit hash sets
 };
 
 // What survives the per-chunk clearing of dcn_status: one per host batch in flight, one per context for the
@@ -109,7 +106,7 @@ struct dcn_batch_report {
     uint32_t overflow;                     // a chunk dropped hit records: its multi-wave units were decided from
                                            // truncated records and its counters were skipped
     uint32_t reserved;
-    unsigned long long need;               // record capacity that would have sufficed (fullest shard x shards)
+    unsigned long long need;               // record capacity (set slots / 4) that would have sufficed
     unsigned long long stats[DCN_N_STATS]; // the six ProcessingStats counters
 };
 
@@ -135,12 +132,12 @@ struct dcn_scan_args {
     uint8_t *keep;
     uint32_t *hits, *total;
     uint8_t *unit_state; // 1 = resolved by the scan kernel
-    // outputs for units spanning several waves
-    uint32_t *g_total;  // per unit, atomically accumulated
-    uint32_t *g_hitcnt; // per unit, number of hit records
-    uint32_t *rec_unit;
-    uint64_t *rec_hash;
-    uint64_t rec_capacity; // total; each shard owns rec_capacity / DCN_REC_SHARDS consecutive entries
+    // outputs for units spanning several waves (or too large for the in-wave hit ring)
+    uint32_t *g_total;   // per unit, atomically accumulated
+    uint32_t *g_hitcnt;  // per unit: hit count, only maintained for units whose tiles are not contiguous
+    uint32_t *g_zero;    // per unit: the zero hash was a hit
+    uint64_t *rec_hash;  // one slot per base of the batch stream: tile t's hits fill [scan_start + carry, ...) in order
+    uint32_t *tile_hits; // per tile: length of that run
     dcn_status *status;
     // dump mode (dcn_minimizer_hashes_batch): per emitted minimizer
     uint64_t *dump_hash;

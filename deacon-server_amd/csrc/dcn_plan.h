@@ -26,14 +26,17 @@ struct dcn_plan_args {
 };
 
 struct dcn_distinct_args {
-    const uint32_t *rec_unit;
-    const uint64_t *rec_hash;
-    uint64_t rec_capacity;
+    const dcn_tile *tiles;
+    const uint32_t *n_tiles;         // device-side tile count
+    const uint32_t *unit_tile_first; // n_units
+    const uint32_t *unit_tile_count; // n_units; 0xFFFFFFFF: not contiguous (hit count in g_hitcnt, always a global set)
+    const uint8_t *unit_state;       // 1 = finished by the scan kernel
+    const uint32_t *tile_hits;       // per tile: length of its run in rec_hash
+    const uint64_t *rec_hash;        // runs of hit hashes, 0 = no entry
     const uint32_t *g_hitcnt;
     uint32_t *g_distinct;
-    uint32_t *g_zero;
-    uint32_t *set_off; // n_units: first slot of a unit's region (only for units with records)
-    uint32_t *caps;    // n_units: region size (power of two), 0 = no records
+    uint32_t *set_off; // n_units: first slot of a unit's global set (only for units with caps != 0)
+    uint32_t *caps;    // n_units: global set size (power of two), 0 = none (counted in LDS, or no hits)
     uint64_t *set_slots;
     uint64_t set_capacity;
     uint32_t n_units;
@@ -45,7 +48,7 @@ struct dcn_finish_args {
     const uint32_t *unit_first_read; // null: unit == read
     const uint64_t *offsets;         // null: no counters (hash seam)
     const uint8_t *unit_state;
-    const uint32_t *g_total, *g_distinct;
+    const uint32_t *g_total, *g_distinct, *g_zero;
     uint64_t abs_threshold;
     double rel_threshold;
     uint32_t deplete;
@@ -57,14 +60,16 @@ struct dcn_finish_args {
 
 struct dcn_probe_hashes_args {
     dcn_table_view table;
-    const uint64_t *hashes;
+    uint64_t *hashes; // device copy of the request's hashes; misses are overwritten with 0
     const uint64_t *hash_offsets;
     uint64_t n_hashes;
     uint32_t n_units;
-    uint32_t *g_total, *g_hitcnt;
-    uint32_t *rec_unit;
-    uint64_t *rec_hash;
-    uint64_t rec_capacity;
+    // one pseudo-tile per unit, so that the distinct pass of the scan path serves this seam too
+    dcn_tile *tiles;
+    uint32_t *n_tiles;
+    uint32_t *tile_hits, *unit_tile_first, *unit_tile_count;
+    uint8_t *unit_state;
+    uint32_t *g_total, *g_hitcnt, *g_distinct, *g_zero;
     dcn_status *status;
 };
 

@@ -4,6 +4,8 @@
 #include "dcn_plan.h"
 #include "dcn_probe.h"
 
+#include <algorithm>
+
 namespace {
 
 // ---- A1: effective sequence -> number of windows (src/filter_common.rs:217-229) -------------------------
@@ -144,91 +146,156 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     }
 }
 
-// ---- exact distinct-hit count from (unit, hash) records ------------------------------------------------------
-// (every kernel of the distinct pass returns at once when no hit record was appended in this batch)
-// A unit with hit records gets a power-of-two region of >= 2x its record count; regions are handed out from one
-// cursor in whatever order the units arrive (only units spanning waves have records, so the atomics are few).
-__global__ __launch_bounds__(256) void distinct_cap_kernel(const uint32_t *g_hitcnt, uint32_t n_units, uint32_t *caps,
-                                                          uint32_t *set_off, dcn_status *status) {
-    if (status->any_records == 0) return;
-    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_units) return;
-    uint32_t hc = g_hitcnt[u];
-    uint32_t cap = 0;
-    if (hc) {
-        cap = 2;
-        while (cap < 2u * hc && cap < (1u << 31)) cap <<= 1;
-        set_off[u] = (uint32_t)atomicAdd(&status->set_cursor, (unsigned long long)cap);
-    }
-    caps[u] = cap;
+// ---- exact distinct-hit count of the units the scan kernel did not finish ------------------------------------
+// (long reads, pairs cut by a wave boundary, units with more hits than the in-wave ring holds.)  The scan kernel left
+// every such unit's hits as per-tile runs in the record array (scan.hip): tile t's run starts at slot
+// scan_start + carry and holds tile_hits[t] hashes, 0 standing for "no entry" (a zero-hash hit is flagged in g_zero).
+//
+// Pass A, one wave per pending unit: sum the unit's run lengths; up to DCN_LDS_SET_MAX hits are deduplicated in an
+// LDS hash set right here -- no global atomics at all, which is where the old (unit, hash) CAS pass spent 0.64 ms per
+// 600 Mbp of long reads.  A larger unit (a read of several hundred kbp from the indexed genome) gets a region of the
+// global set scratch instead, so that pass B can spread its runs over the whole chip.
+// Every kernel here returns at once when the scan wrote no run (batches of short single reads).
+constexpr uint32_t DCN_LDS_SET_SLOTS = 4096; // 32 KB
+constexpr uint32_t DCN_LDS_SET_MAX = 2800;   // hits deduplicated in LDS (load <= 0.68)
+
+__device__ inline uint32_t set_slot_of(uint64_t h, uint32_t cap) {
+    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
+    return ((lo ^ ((hi << 13) | (hi >> 19))) * 0x85EBCA6Bu) & (cap - 1);
 }
 
-__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, const dcn_status *status) {
-    if (status->any_records == 0) return;
+__global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) {
+    __shared__ unsigned long long set[DCN_LDS_SET_SLOTS];
+    if (a.status->any_records == 0) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t NT = *a.n_tiles;
+    for (uint32_t ubase = blockIdx.x * 64; ubase < a.n_units; ubase += gridDim.x * 64) {
+        const uint32_t mine = ubase + lane;
+        unsigned long long pending = __ballot(mine < a.n_units && a.unit_state[mine] == 0);
+        while (pending) {
+            const uint32_t u = ubase + (uint32_t)__ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            const uint32_t first = a.unit_tile_first[u], count = a.unit_tile_count[u];
+            const bool contiguous = count != 0xFFFFFFFFu;
+            uint32_t H = 0;
+            if (contiguous) {
+                for (uint32_t i = lane; i < count; i += 64) H += first + i < NT ? a.tile_hits[first + i] : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) H += __shfl_xor(H, d, 64);
+            } else {
+                H = a.g_hitcnt[u];
+            }
+            if (H == 0) {
+                if (lane == 0) a.caps[u] = 0;
+                continue;
+            }
+            if (!contiguous || H > DCN_LDS_SET_MAX) {
+                // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor
+                if (lane == 0) {
+                    uint32_t cap = 64;
+                    while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
+                    a.set_off[u] = (uint32_t)atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
+                    a.caps[u] = cap;
+                    a.status->any_big = 1;
+                }
+                continue;
+            }
+            uint32_t cap = 64;
+            while (cap < 2u * H) cap <<= 1;
+            if (cap > DCN_LDS_SET_SLOTS) cap = DCN_LDS_SET_SLOTS;
+            for (uint32_t i = lane; i < cap; i += 64) set[i] = 0;
+            __syncthreads();
+            uint32_t distinct = 0;
+            // four tiles per step, 16 lanes each: their loads are in flight together
+            const uint32_t grp = lane >> 4, sub = lane & 15;
+            for (uint32_t t0 = 0; t0 < count; t0 += 4) {
+                const uint32_t ti = t0 + grp;
+                uint32_t n = 0;
+                uint64_t slot0 = 0;
+                if (ti < count) {
+                    n = a.tile_hits[first + ti];
+                    const dcn_tile tl = a.tiles[first + ti];
+                    slot0 = tl.scan_start + (tl.flags & 1u);
+                }
+                uint32_t nmax = n;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor(nmax, d, 64));
+                for (uint32_t j = sub; j < nmax + sub; j += 16) { // wave-uniform trip count
+                    const bool act = j < n;
+                    const uint64_t h = act ? a.rec_hash[slot0 + j] : 0ull;
+                    bool fresh = false;
+                    if (act && h != 0) {
+                        uint32_t sl = set_slot_of(h, cap);
+                        for (;;) {
+                            unsigned long long old = atomicCAS(&set[sl], 0ull, (unsigned long long)h);
+                            if (old == 0) {
+                                fresh = true;
+                                break;
+                            }
+                            if (old == h) break;
+                            sl = (sl + 1) & (cap - 1);
+                        }
+                    }
+                    distinct += (uint32_t)__popcll(__ballot(fresh));
+                }
+            }
+            __syncthreads();
+            if (lane == 0) {
+                a.g_distinct[u] = distinct; // the zero-hash flag is added by the finish kernel
+                a.caps[u] = 0;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, dcn_status *status) {
+    if (status->any_big == 0) return;
     uint64_t total = status->set_cursor;
-    if (total > capacity) total = capacity;
+    if (total > capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) status->rec_overflow = 1;
+        return;
+    }
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) set_slots[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void distinct_insert_kernel(dcn_distinct_args a) {
-    if (a.status->any_records == 0) return;
-    uint64_t total_slots = a.status->set_cursor;
-    if (total_slots > a.set_capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.status->rec_overflow = 1;
-        return;
-    }
-    const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1;
-    // blocks are dealt round-robin over the shards; within a shard a grid-stride loop in whole waves
-    for (uint32_t shard = blockIdx.x % DCN_REC_SHARDS; shard < DCN_REC_SHARDS; shard += DCN_REC_SHARDS) {
-        unsigned long long n = a.status->rec_count[shard];
-        if (n > seg) n = seg;
-        const uint32_t blocks_per_shard = gridDim.x / DCN_REC_SHARDS;
-        const uint64_t stride = (uint64_t)blocks_per_shard * blockDim.x;
-        const uint64_t first = (uint64_t)(blockIdx.x / DCN_REC_SHARDS) * blockDim.x + threadIdx.x;
-        for (uint64_t i0 = first - lane; i0 < n; i0 += stride) { // i0: wave-uniform base
-            const uint64_t i = i0 + lane;
+// Pass B, one wave per tile of a unit with a global set: CAS-insert the tile's run, one atomicAdd of the number of
+// new keys per tile.
+__global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
+    if (a.status->any_big == 0 || a.status->set_cursor > a.set_capacity) return;
+    const uint32_t NT = *a.n_tiles;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t t = wave; t < NT; t += n_waves) {
+        const dcn_tile tl = a.tiles[t];
+        if (a.unit_state[tl.unit]) continue;
+        const uint32_t cap = a.caps[tl.unit];
+        if (!cap) continue;
+        const uint32_t n = a.tile_hits[t];
+        unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[tl.unit]);
+        const uint64_t slot0 = tl.scan_start + (tl.flags & 1u);
+        uint32_t fresh_n = 0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+            const uint32_t j = j0 + lane;
             bool fresh = false;
-            uint32_t u = 0xFFFFFFFFu;
-            if (i < n) {
-                u = a.rec_unit[shard * seg + i];
-                uint64_t h = a.rec_hash[shard * seg + i];
-                if (h == 0) { // 0 marks an empty slot: a zero hash is tracked by a per-unit flag
-                    fresh = atomicExch(&a.g_zero[u], 1u) == 0u;
-                } else {
-                    uint32_t cap = a.caps[u];
-                    unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
-                    uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
-                    uint32_t slot = ((lo ^ ((hi << 13) | (hi >> 19))) * 0x85EBCA6Bu) & (cap - 1);
+            if (j < n) {
+                const uint64_t h = a.rec_hash[slot0 + j];
+                if (h != 0) {
+                    uint32_t sl = set_slot_of(h, cap);
                     for (;;) {
-                        unsigned long long old = atomicCAS(&region[slot], 0ull, (unsigned long long)h);
+                        unsigned long long old = atomicCAS(&region[sl], 0ull, (unsigned long long)h);
                         if (old == 0) {
                             fresh = true;
                             break;
                         }
                         if (old == h) break;
-                        slot = (slot + 1) & (cap - 1);
+                        sl = (sl + 1) & (cap - 1);
                     }
                 }
             }
-            // one atomicAdd per run of equal unit among the lanes with a new key (records of a wave round are
-            // adjacent and mostly of one unit)
-            const unsigned long long fb = __ballot(fresh);
-            if (fb) {
-                const unsigned long long below = fb & lt;
-                const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
-                const uint32_t prev_u = __shfl(u, prev_lane, 64);
-                const bool run_head = fresh && (below == 0 || prev_u != u);
-                const unsigned long long hm = __ballot(run_head);
-                if (run_head) {
-                    const unsigned long long later = hm & ~((2ull << lane) - 1);
-                    const unsigned long long upto = later ? ((1ull << (__ffsll((long long)later) - 1)) - 1) : ~0ull;
-                    atomicAdd(&a.g_distinct[u], (uint32_t)__popcll(fb & upto & ~lt));
-                }
-            }
+            fresh_n += (uint32_t)__popcll(__ballot(fresh));
         }
+        if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[tl.unit], fresh_n);
     }
 }
 
@@ -243,7 +310,7 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
         if (a.unit_state[u]) {
             keep = a.keep[u] != 0;
         } else {
-            uint32_t tot = a.g_total[u], hc = a.g_distinct[u];
+            uint32_t tot = a.g_total[u], hc = a.g_distinct[u] + (a.g_zero[u] ? 1u : 0u);
             keep = dcn_decide(hc, tot, a.abs_threshold, a.rel_threshold, a.deplete);
             a.keep[u] = keep ? 1 : 0;
             if (a.hits) a.hits[u] = hc;
@@ -265,15 +332,9 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
     }
     if (a.status->rec_overflow) {
         // sticky: the status words are cleared before the next chunk, the report is read when the batch is waited for
-        if (blockIdx.x == 0 && threadIdx.x < 64) {
-            unsigned long long need = 0;
-            for (uint32_t sidx = threadIdx.x; sidx < DCN_REC_SHARDS; sidx += 64) need = max(need, a.status->rec_count[sidx]);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) need = max(need, (unsigned long long)__shfl_xor((long long)need, d, 64));
-            if (threadIdx.x == 0) {
-                a.report->overflow = 1;
-                atomicMax(&a.report->need, need * DCN_REC_SHARDS);
-            }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            a.report->overflow = 1;
+            atomicMax(&a.report->need, (a.status->set_cursor + 3) / 4);
         }
         return; // an overflowed attempt is re-run: do not count it
     }
@@ -295,37 +356,52 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
 }
 
 // ---- server seam: probe precomputed hashes (src/remote_filter.rs:230-301) ------------------------------------
+// Every unit becomes one pseudo-tile whose run is its own slice of the hash array: the probe kernel overwrites each
+// hash that is not in the index with 0 ("no entry"), and the distinct pass above does the rest.
 __global__ __launch_bounds__(256) void probe_hashes_kernel(dcn_probe_hashes_args a) {
-    uint64_t n = a.n_hashes;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t shard = blockIdx.x % DCN_REC_SHARDS;
-    const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_hashes; i += stride) {
         uint64_t h = a.hashes[i];
-        if (!dcn_table_contains_dev(a.table, h)) continue;
-        // unit = largest u with hash_offsets[u] <= i
-        uint32_t lo = 0, hi = a.n_units - 1;
-        while (lo < hi) {
-            uint32_t mid = lo + (hi - lo + 1) / 2;
-            if (a.hash_offsets[mid] <= i) lo = mid;
-            else hi = mid - 1;
+        if (h == 0) {
+            if (a.table.has_zero) {
+                // unit = largest u with hash_offsets[u] <= i
+                uint32_t lo = 0, hi = a.n_units - 1;
+                while (lo < hi) {
+                    uint32_t mid = lo + (hi - lo + 1) / 2;
+                    if (a.hash_offsets[mid] <= i) lo = mid;
+                    else hi = mid - 1;
+                }
+                a.g_zero[lo] = 1;
+            }
+        } else if (!dcn_table_contains_dev(a.table, h)) {
+            a.hashes[i] = 0;
         }
-        unsigned long long r = atomicAdd(&a.status->rec_count[shard], 1ull);
-        a.status->any_records = 1;
-        if (r < seg) {
-            a.rec_unit[shard * seg + r] = lo;
-            a.rec_hash[shard * seg + r] = h;
-        } else {
-            a.status->rec_overflow = 1;
-        }
-        atomicAdd(&a.g_hitcnt[lo], 1u);
     }
 }
 
-__global__ __launch_bounds__(256) void hash_totals_kernel(const uint64_t *hash_offsets, uint32_t n_units,
-                                                         uint32_t *g_total) {
+__global__ __launch_bounds__(256) void hash_units_kernel(dcn_probe_hashes_args a) {
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u < n_units) g_total[u] = (uint32_t)(hash_offsets[u + 1] - hash_offsets[u]);
+    if (u == 0) {
+        *a.n_tiles = a.n_units;
+        a.status->any_records = 1;
+    }
+    if (u >= a.n_units) return;
+    const uint64_t n = a.hash_offsets[u + 1] - a.hash_offsets[u];
+    dcn_tile t;
+    t.scan_start = a.hash_offsets[u];
+    t.read_pos = 0;
+    t.unit = u;
+    t.n_windows = (uint32_t)n;
+    t.flags = 0;
+    a.tiles[u] = t;
+    a.tile_hits[u] = (uint32_t)n;
+    a.unit_tile_first[u] = u;
+    a.unit_tile_count[u] = 1;
+    a.unit_state[u] = 0;
+    a.g_total[u] = (uint32_t)n;
+    a.g_hitcnt[u] = 0;
+    a.g_distinct[u] = 0;
+    a.g_zero[u] = 0;
 }
 
 inline uint32_t blocks_for(uint64_t n, uint32_t cap = 256 * 16) {
@@ -346,10 +422,10 @@ int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream) {
 }
 
 int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream) {
-    hipLaunchKernelGGL(distinct_cap_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a.g_hitcnt,
-                       a.n_units, a.caps, a.set_off, a.status);
+    uint32_t groups = (a.n_units + 63) / 64;
+    hipLaunchKernelGGL(unit_distinct_kernel, dim3(std::max(1u, std::min(groups, 256u * 20u))), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_capacity, a.status);
-    hipLaunchKernelGGL(distinct_insert_kernel, dim3(DCN_REC_SHARDS * 32), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(big_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }
@@ -361,8 +437,7 @@ int dcn_launch_finish(const dcn_finish_args &a, hipStream_t stream) {
 }
 
 int dcn_launch_probe_hashes(const dcn_probe_hashes_args &a, hipStream_t stream) {
-    hipLaunchKernelGGL(hash_totals_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a.hash_offsets,
-                       a.n_units, a.g_total);
+    hipLaunchKernelGGL(hash_units_kernel, dim3((a.n_units + 255) / 256), dim3(256), 0, stream, a);
     if (a.n_hashes)
         hipLaunchKernelGGL(probe_hashes_kernel, dim3(blocks_for(a.n_hashes)), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());

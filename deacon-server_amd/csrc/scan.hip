@@ -61,8 +61,10 @@ struct WaveShared {
     uint32_t hraw[DCN_WAVE];            // per unit slot: hits pushed through the ring so far
     uint32_t unit_of[DCN_WAVE];         // unit slot -> global unit id
     uint16_t start[DCN_WAVE + 2];       // exclusive prefix of the per-lane list lengths
+    uint32_t thits[DCN_WAVE];           // per lane (tile): hits written to the tile's run of the record array so far
     uint8_t local[DCN_WAVE];            // unit slot has all its tiles in this wave
     uint8_t lok[DCN_WAVE];              // unit slot is being resolved inside this wave
+    uint8_t ncont[DCN_WAVE];            // unit slot's tiles are not contiguous (a unit cut by a planning block)
 };
 
 #ifndef DCN_EXP
@@ -125,14 +127,17 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     sh.items[lane] = 0;
     sh.hraw[lane] = 0;
     sh.lok[lane] = 0;
+    sh.thits[lane] = 0;
     if (head) {
         sh.unit_of[uslot] = t.unit;
-        bool loc = false;
+        bool loc = false, nc = false;
         if (!DUMP) {
             uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
-            loc = count != 0xFFFFFFFFu && first >= wave_first && first + count <= wave_first + DCN_WAVE;
+            nc = count == 0xFFFFFFFFu;
+            loc = !nc && first >= wave_first && first + count <= wave_first + DCN_WAVE;
         }
         sh.local[uslot] = loc ? 1 : 0;
+        sh.ncont[uslot] = nc ? 1 : 0;
     }
     if (lane < 16) {
         uint32_t in = lane & 3, out = lane >> 2;
@@ -174,6 +179,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     uint32_t prev = 0xFFFFFFFFu;   // previous window's choice (dedup state)
     uint32_t n_ring = 0;           // wave-uniform: hits pushed through the LDS ring so far
     bool go_global = false;        // wave-uniform: no unit of this wave is resolved in-wave any more
+    bool any_rec = false;          // wave-uniform: this wave wrote a hit into some tile's run
     const uint32_t nk = nwc ? nwc + w - 1 : 0;
     const uint32_t jmax = wave_max_u32(nk);
 
@@ -355,45 +361,33 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     n_ring += nh;
                     __syncthreads();
                 }
-                // hits of every other unit: exported as (unit, hash) records into this workgroup's shard of the
-                // record buffer; the per-unit record count is added once per run of equal unit, not per record
+                // hits of every other unit: appended to the owner TILE's run of the record array.  Tile t owns the
+                // slots [scan_start + carry, + n_windows) (one per window, so a run can never overflow and runs of
+                // different tiles never overlap); its hits fill the run from the front in item order.  No global
+                // atomics: the running count of a tile lives in LDS, and since items are in flat order the hits of
+                // one tile sit in adjacent lanes of a round.  plan.hip's distinct pass reads the runs back.
+                // A zero hash (0 marks an empty set slot there) is flagged per unit instead of recorded.
                 {
                     const bool rec = hit[u] && !lok;
                     const unsigned long long rb = __ballot(rec);
                     if (rb) { // wave-uniform
                         const unsigned long long lt = (1ull << lane) - 1;
-                        const uint32_t nrec = (uint32_t)__popcll(rb);
-                        const uint32_t shard = blockIdx.x % DCN_REC_SHARDS;
-                        const unsigned long long seg = a.rec_capacity / DCN_REC_SHARDS;
-                        unsigned long long base = 0;
-                        if (lane == 0) {
-                            base = atomicAdd(&a.status->rec_count[shard], (unsigned long long)nrec);
-                            a.status->any_records = 1;
-                        }
-                        base = __shfl(base, 0, 64);
-                        const uint32_t rank = (uint32_t)__popcll(rb & lt);
                         const unsigned long long below = rb & lt;
                         const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
-                        const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
-                        const bool run_head = rec && (below == 0 || prev_us != o_uslot[u]);
-                        const unsigned long long hm = __ballot(run_head);
+                        const uint32_t prev_owner = __shfl(lo[u], prev_lane, 64);
+                        const bool run_head = rec && (below == 0 || prev_owner != lo[u]);
+                        const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
+                        const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
+                        const uint32_t rank = (uint32_t)__popcll(below) - (uint32_t)__popcll(rb & ((1ull << head_lane) - 1));
+                        const long long o_s = __shfl((long long)s, lo[u], 64);
+                        const uint32_t o_carry = __shfl(carry, lo[u], 64);
+                        any_rec = true;
                         if (rec) {
-                            const unsigned long long ridx = base + rank;
-                            const uint32_t gu = sh.unit_of[o_uslot[u]];
-                            if (ridx < seg) {
-                                a.rec_unit[shard * seg + ridx] = gu;
-                                a.rec_hash[shard * seg + ridx] = hash[u];
-                            } else {
-                                a.status->rec_overflow = 1;
-                            }
-                            if (run_head) {
-                                // run = rec lanes from this head up to the next head
-                                const unsigned long long later_heads = hm & ~((2ull << lane) - 1);
-                                const uint32_t end_rank = later_heads ? (uint32_t)__popcll(rb & ((1ull << (__ffsll((long long)later_heads) - 1)) - 1))
-                                                                      : nrec;
-                                atomicAdd(&a.g_hitcnt[gu], end_rank - rank);
-                            }
+                            const uint32_t before = sh.thits[lo[u]];
+                            a.rec_hash[(uint64_t)o_s + o_carry + before + rank] = hash[u];
+                            if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
+                        if (rec) atomicAdd(&sh.thits[lo[u]], 1u); // after every lane of the run has read the old count
                     }
                 }
             }
@@ -713,6 +707,14 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     if (DUMP) {
         if (have_tile) a.dump_count[tile_idx] = emitted_before;
         return;
+    }
+
+    // ---- hit runs of the tiles whose unit is finished by the distinct pass --------------------------------------
+    if (any_rec && lane == 0) a.status->any_records = 1;
+    if (have_tile && !sh.lok[uslot]) {
+        const uint32_t th = sh.thits[lane];
+        a.tile_hits[tile_idx] = th;
+        if (th && sh.ncont[uslot]) atomicAdd(&a.g_hitcnt[t.unit], th); // no tile list to sum over: count here
     }
 
     // ---- results of the units this wave owns --------------------------------------------------------------

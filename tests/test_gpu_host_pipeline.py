@@ -170,6 +170,7 @@ def test_record_overflow_in_a_pipelined_batch_is_rerun(oracle, dcn, genome, inde
     """long reads overflow the small default record scratch of a small context in some chunks; wait() grows it and
     runs the batch again, counters counted once"""
     small_chunks(monkeypatch, 100_000)
+    monkeypatch.setenv("DCN_RECORD_CAPACITY", "64")  # no room for the global sets of units with > 2800 hits
     oidx, gidx = index_pair
     reads = [genome[i * 10_000:i * 10_000 + 60_000] for i in range(8)] + [genome[:50_000]] * 2
     reads += sample_reads(np.random.default_rng(131), genome, 500, 50, 150)
@@ -185,9 +186,10 @@ def test_record_overflow_in_a_pipelined_batch_is_rerun(oracle, dcn, genome, inde
     proc.close()
 
 
-def test_sticky_overflow_of_the_device_pointer_api(oracle, dcn, genome, index_pair):
+def test_sticky_overflow_of_the_device_pointer_api(oracle, dcn, genome, index_pair, monkeypatch):
     """an overflow in batch N must not be erased by the status clearing of batch N+1"""
     torch = pytest.importorskip("torch")
+    monkeypatch.setenv("DCN_RECORD_CAPACITY", "64")
     oidx, gidx = index_pair
     dev = torch.device("cuda:0")
     big = [genome[:120_000]] * 6

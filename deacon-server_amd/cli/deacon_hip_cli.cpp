@@ -34,6 +34,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <string>
 #include <thread>
 #include <vector>
@@ -152,6 +153,11 @@ struct Batch {
     std::vector<Rec> recs;
     std::vector<uint8_t> keep;
     std::vector<uint32_t> hits, total;
+    // the calls this batch was cut into (normally one): sequence numbers handed out by the multi-GPU driver and the
+    // rebased offsets / unit ids of the later pieces, alive until the calls are waited for
+    std::vector<uint64_t> gpu_seqs;
+    std::vector<std::vector<uint64_t>> sub_off;
+    std::vector<std::vector<uint32_t>> sub_uid;
     bool paired = false;
     void clear() {
         text.clear();
@@ -515,6 +521,7 @@ struct FilterArgs {
     bool deplete = false, rename = false, debug = false, quiet = false;
     size_t threads = 8;
     int compression_level = 2;
+    std::vector<int> devices{0};  // --gpus N / --devices a,b,...: one pipeline context per entry (repeats allowed)
 };
 
 // --debug lines of process_record / process_record_pair (src/local_filter.rs:354-363, 424-434).  Single reads list
@@ -700,7 +707,7 @@ int run_filter(const FilterArgs &a) {
     // The parsers are already running: HIP start-up (~0.25 s) and the index load happen behind them.
     std::unique_ptr<deacon::Index> index_holder;
     try {
-        index_holder.reset(new deacon::Index(deacon::Index::load(a.index)));
+        index_holder.reset(new deacon::Index(deacon::Index::load(a.index, a.devices[0])));
     } catch (const std::exception &e) {
         die(e.what());
     }
@@ -736,14 +743,22 @@ int run_filter(const FilterArgs &a) {
         }
     });
 
-    // ---- stage 2: the GPU, on its own thread(s); batches leave the stage in input order and the --rename numbering
-    // is done on this thread
-    // (each thread creates its context on its first batch, ~0.1 s that overlaps the other thread and the parsers)
-    std::mutex procs_m;
-    std::vector<std::unique_ptr<deacon::FilterProcessor>> procs;  // owned here so they outlive the worker threads' use
-    size_t n_gpu_threads = 1;  // two (own context each) overlap copies with kernels but measured no faster end to end
-    if (const char *e = std::getenv("DCN_CLI_GPU_THREADS")) n_gpu_threads = std::atoi(e) == 2 ? 2 : 1;  // tuning hook
-    OrderedStage gpu_stage(n_gpu_threads, n_gpu_threads + 2, [&](Batch &b) {
+    // ---- stage 2: the GPUs.  deacon::MultiGpuFilter runs one host thread + pipeline context per entry of
+    // a.devices (index replicated device to device), deals the calls round-robin and keeps two of them in flight
+    // per context, so a call's PCIe copy overlaps its predecessor's kernels.  The feeder thread submits, this
+    // thread waits for the calls in submission order: batches leave the stage in input order (the --rename
+    // numbering is done here).  Counterpart of the worker pool of run(), src/local_filter.rs:696-709.
+    std::unique_ptr<deacon::MultiGpuFilter> multi;
+    try {
+        multi.reset(new deacon::MultiGpuFilter(index, a.devices, cfg));
+    } catch (const std::exception &e) {
+        die(e.what());
+    }
+    Queue<std::unique_ptr<Batch>> submitted(2 * a.devices.size() + 2);
+    auto submit_batch = [&](Batch &b) {
+        b.gpu_seqs.clear();
+        b.sub_off.clear();
+        b.sub_uid.clear();
         if (b.recs.empty()) return;
         StageClock::Scope sc(t_gpu);
         size_t n_units = b.paired ? b.recs.size() / 2 : b.recs.size();
@@ -752,50 +767,49 @@ int run_filter(const FilterArgs &a) {
             b.hits.assign(n_units, 0);
             b.total.assign(n_units, 0);
         }
-        static thread_local deacon::FilterProcessor *p = nullptr;
-        try {
-            if (!p) {
-                std::unique_ptr<deacon::FilterProcessor> fresh(new deacon::FilterProcessor(index, cfg));
-                p = fresh.get();
-                std::lock_guard<std::mutex> l(procs_m);
-                procs.push_back(std::move(fresh));
-            }
-            // a parsed chunk normally fits one call; chunks of very short or very long records are cut at unit
-            // boundaries into calls that fit the context
-            const size_t n = b.recs.size(), per = b.paired ? 2 : 1;
-            std::vector<uint64_t> sub_off;
-            std::vector<uint32_t> sub_uid;
-            for (size_t r0 = 0; r0 < n;) {
-                size_t r1 = r0;
-                while (r1 < n && (r1 - r0) + per <= cfg.max_batch_reads && b.offsets[r1 + per] - b.offsets[r0] <= cfg.max_batch_bases)
-                    r1 += per;
-                if (r1 == r0) die("a single record is longer than the largest batch (" + std::to_string(cfg.max_batch_bases) + " bases)");
-                const size_t u0 = r0 / per;
-                const uint64_t *off = b.offsets.data();
-                const uint32_t *uid = b.paired ? b.unit_id.data() : nullptr;
-                if (r0 != 0) {  // offsets and unit ids of a later piece start from zero again
-                    sub_off.resize(r1 - r0 + 1);
-                    for (size_t r = r0; r <= r1; ++r) sub_off[r - r0] = b.offsets[r] - b.offsets[r0];
-                    off = sub_off.data();
-                    if (b.paired) {
-                        sub_uid.resize(r1 - r0);
-                        for (size_t r = r0; r < r1; ++r) sub_uid[r - r0] = b.unit_id[r] - b.unit_id[r0];
-                        uid = sub_uid.data();
-                    }
+        // a parsed chunk normally fits one call; chunks of very short or very long records are cut at unit
+        // boundaries into calls that fit the context
+        const size_t n = b.recs.size(), per = b.paired ? 2 : 1;
+        for (size_t r0 = 0; r0 < n;) {
+            size_t r1 = r0;
+            while (r1 < n && (r1 - r0) + per <= cfg.max_batch_reads && b.offsets[r1 + per] - b.offsets[r0] <= cfg.max_batch_bases)
+                r1 += per;
+            if (r1 == r0) die("a single record is longer than the largest batch (" + std::to_string(cfg.max_batch_bases) + " bases)");
+            const size_t u0 = r0 / per;
+            deacon::MultiGpuFilter::Job job;
+            job.bases = b.bases.data() + b.offsets[r0];
+            job.offsets = b.offsets.data();
+            job.unit_id = b.paired ? b.unit_id.data() : nullptr;
+            if (r0 != 0) {  // offsets and unit ids of a later piece start from zero again
+                b.sub_off.emplace_back(r1 - r0 + 1);
+                for (size_t r = r0; r <= r1; ++r) b.sub_off.back()[r - r0] = b.offsets[r] - b.offsets[r0];
+                job.offsets = b.sub_off.back().data();
+                if (b.paired) {
+                    b.sub_uid.emplace_back(r1 - r0);
+                    for (size_t r = r0; r < r1; ++r) b.sub_uid.back()[r - r0] = b.unit_id[r] - b.unit_id[r0];
+                    job.unit_id = b.sub_uid.back().data();
                 }
-                p->filter_batch(b.bases.data() + b.offsets[r0], off, uid, (uint32_t)(r1 - r0), b.keep.data() + u0,
-                                a.debug ? b.hits.data() + u0 : nullptr, a.debug ? b.total.data() + u0 : nullptr);
-                r0 = r1;
+            }
+            job.n_reads = (uint32_t)(r1 - r0);
+            job.keep = b.keep.data() + u0;
+            job.hits = a.debug ? b.hits.data() + u0 : nullptr;
+            job.total = a.debug ? b.total.data() + u0 : nullptr;
+            b.gpu_seqs.push_back(multi->submit(job));
+            r0 = r1;
+        }
+    };
+    std::unique_ptr<deacon::FilterProcessor> debug_proc;  // only --debug re-scans batches (for the k-mer strings)
+    std::thread feeder([&] {
+        std::unique_ptr<Batch> b;
+        try {
+            while (next_parsed(b)) {
+                submit_batch(*b);
+                submitted.push(std::move(b));
             }
         } catch (const std::exception &e) {
             die(e.what());
         }
-    });
-    std::unique_ptr<deacon::FilterProcessor> debug_proc;  // only --debug re-scans batches (for the k-mer strings)
-    std::thread feeder([&] {
-        std::unique_ptr<Batch> b;
-        while (next_parsed(b)) gpu_stage.push(std::move(b));
-        gpu_stage.finish();
+        submitted.finish();
         m_feeder_done = std::chrono::duration<double>(clock::now() - start).count();
     });
     {
@@ -804,7 +818,12 @@ int run_filter(const FilterArgs &a) {
         for (;;) {
             {
                 StageClock::Scope sc(t_gpu_wait);
-                if (!gpu_stage.pop(b)) break;
+                if (!submitted.pop(b)) break;
+                try {
+                    for (uint64_t seq : b->gpu_seqs) multi->wait(seq);
+                } catch (const std::exception &e) {
+                    die(e.what());
+                }
             }
             if (b->recs.empty()) continue;
             size_t n_units = b->paired ? b->recs.size() / 2 : b->recs.size();
@@ -1051,6 +1070,22 @@ int main(int argc, char **argv) {
                 else if (s == "--compression-level") a.compression_level = std::atoi(need(++i).c_str());
                 else if (s == "--debug") a.debug = true;
                 else if (s == "-q" || s == "--quiet") a.quiet = true;
+                else if (s == "--gpus") {  // GPUs 0..N-1, one pipeline context each
+                    int n = std::atoi(need(++i).c_str());
+                    if (n < 1 || n > 64) die("invalid value for --gpus: must be 1..64");
+                    a.devices.clear();
+                    for (int d = 0; d < n; ++d) a.devices.push_back(d);
+                } else if (s == "--devices") {  // explicit list, repeats allowed: 0,0 = two contexts on GPU 0
+                    a.devices.clear();
+                    std::stringstream ss(need(++i));
+                    for (std::string tok; std::getline(ss, tok, ',');) {
+                        char *end = nullptr;
+                        long d = std::strtol(tok.c_str(), &end, 10);
+                        if (tok.empty() || *end || d < 0 || d > 1023) die("invalid value for --devices: '" + tok + "'");
+                        a.devices.push_back((int)d);
+                    }
+                    if (a.devices.empty() || a.devices.size() > 64) die("invalid value for --devices");
+                }
                 else if (s.size() > 1 && s[0] == '-' && s != "-") die("unexpected argument '" + s + "'");
                 else pos.push_back(s);
             }

@@ -235,6 +235,12 @@ extern "C" int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, 
     return DCN_OK;
 }
 
+extern "C" int dcn_index_device(const dcn_index *index, int *device) {
+    if (!index || !device) return dcn_fail(DCN_ERR_ARG, "index/device is NULL");
+    *device = index->device;
+    return DCN_OK;
+}
+
 extern "C" int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n, uint8_t *out) {
     if (!index) return dcn_fail(DCN_ERR_ARG, "index is NULL");
     if (n > 0 && (!keys || !out)) return dcn_fail(DCN_ERR_ARG, "keys/out is NULL");

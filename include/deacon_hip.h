@@ -105,6 +105,9 @@ int dcn_index_diff(const dcn_index *first, const dcn_index *second, dcn_index **
 /* Header fields and the number of DISTINCT keys (what `deacon index info` prints, src/index.rs:539-560). */
 int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n_keys);
 
+/* The HIP device the index lives on. */
+int dcn_index_device(const dcn_index *index, int *device);
+
 /* Set membership for `n` host keys -> out[i] in {0,1}: FxHashSet::contains (src/filter_common.rs:144). */
 int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n, uint8_t *out);
 

@@ -10,6 +10,8 @@
 //     .should_keep_pair(seq1, seq2)                                                      local_filter.rs:254-285
 //     .filter_batch(reads[, paired])    the paraseq per-record loop over one batch       local_filter.rs:346-528
 //     .stats()                          ProcessingStats                                  local_filter.rs:179-187
+//   deacon::MultiGpuFilter              the worker pool of run(): N workers, one set,    local_filter.rs:376-405, 630-631,
+//                                       outputs merged in order, counters summed           696-709
 //   deacon::get_minimizer_hashes_and_positions                                           filter_common.rs:211-310
 //   deacon::unpaired_should_keep / paired_should_keep                                    remote_filter.rs:230-301
 //
@@ -19,10 +21,16 @@
 #define DEACON_HIP_HPP
 
 #include <array>
+#include <condition_variable>
 #include <cstdint>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -97,6 +105,18 @@ class Index {
         std::vector<uint8_t> out(hashes.size());
         check(dcn_index_contains(h_, hashes.data(), hashes.size(), out.data()));
         return std::vector<bool>(out.begin(), out.end());
+    }
+    // replica on another (or the same) device, copied device to device: the reference shares ONE set between its
+    // workers (local_filter.rs:630-631); a multi-GPU host loads it once and clones it
+    Index clone(int device) const {
+        dcn_index *h = nullptr;
+        check(dcn_index_clone(h_, device, &h));
+        return Index(h);
+    }
+    int device() const {
+        int d = 0;
+        check(dcn_index_device(h_, &d));
+        return d;
     }
     const dcn_index *raw() const { return h_; }
 
@@ -224,6 +244,161 @@ class FilterProcessor {
     std::vector<uint8_t> bases_, keep_;
     std::vector<uint64_t> offsets_;
     std::vector<uint32_t> unit_id_, hits_, total_;
+};
+
+// The reference's run() hands record batches to N worker threads that share one set, merges their output buffers
+// under a mutex and sums their ProcessingStats (local_filter.rs:376-405, 630-631, 696-709).  Here a worker is a
+// GPU pipeline context: one host thread + dcn_ctx per entry of `devices` (a device may be listed more than once:
+// {0, 0} runs two contexts on GPU 0), the index loaded once and replicated device to device, batches dealt
+// round-robin by sequence number -- a batch holds whole units, so pairs stay intact and any batch->worker map gives
+// the decisions of the single-context run.  Each worker keeps two batches in flight (dcn_filter_batch_submit /
+// _wait), so copies of one overlap kernels of the other.  Results land in the caller's arrays; wait(seq) in
+// sequence order is the ordered merge.  No collective: all contexts live in this process, the counters are summed
+// on the host (dcn_stats_allreduce); separate processes reduce them with RCCL instead (bench.py).
+class MultiGpuFilter {
+  public:
+    struct Job {  // one batch: the arguments of dcn_filter_batch; every array must stay valid until wait(seq) returns
+        const uint8_t *bases = nullptr;
+        const uint64_t *offsets = nullptr;
+        const uint32_t *unit_id = nullptr;
+        uint32_t n_reads = 0;
+        uint8_t *keep = nullptr;
+        uint32_t *hits = nullptr, *total = nullptr;
+    };
+
+    MultiGpuFilter(const Index &index, const std::vector<int> &devices, const FilterConfig &config,
+                   std::size_t queue_depth = 4)
+        : config_(config), queue_depth_(queue_depth) {
+        if (devices.empty()) throw Error(DCN_ERR_ARG, "MultiGpuFilter: no devices");
+        // one table per distinct device: the caller's index (which must outlive this object) serves its own device,
+        // every other device gets a replica copied device to device
+        std::map<int, const dcn_index *> by_device;
+        by_device[index.device()] = index.raw();
+        for (int d : devices) {
+            if (by_device.count(d)) continue;
+            replicas_.push_back(index.clone(d));
+            by_device[d] = replicas_.back().raw();
+        }
+        for (std::size_t i = 0; i < devices.size(); ++i) workers_.emplace_back(new Worker());
+        for (std::size_t i = 0; i < devices.size(); ++i) {
+            Worker *w = workers_[i].get();
+            check(dcn_ctx_create(by_device[devices[i]], config.max_batch_bases, config.max_batch_reads, &w->ctx));
+            w->thread = std::thread([this, w] { work(*w); });
+        }
+    }
+    MultiGpuFilter(const MultiGpuFilter &) = delete;
+    MultiGpuFilter &operator=(const MultiGpuFilter &) = delete;
+    ~MultiGpuFilter() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &w : workers_) {
+            if (w->thread.joinable()) w->thread.join();
+            if (w->ctx) dcn_ctx_destroy(w->ctx);
+        }
+    }
+
+    std::size_t workers() const { return workers_.size(); }
+
+    // hands the batch to worker seq % N and returns its sequence number; blocks while that worker's queue is full
+    uint64_t submit(const Job &job) {
+        std::unique_lock<std::mutex> l(m_);
+        const uint64_t seq = next_seq_++;
+        Worker &w = *workers_[seq % workers_.size()];
+        cv_.wait(l, [&] { return w.queue.size() < queue_depth_; });
+        w.queue.emplace_back(seq, job);
+        cv_.notify_all();
+        return seq;
+    }
+    // blocks until batch `seq` is done and its outputs are in the caller's arrays; throws what the worker caught
+    void wait(uint64_t seq) {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return done_.count(seq) != 0; });
+        std::pair<int, std::string> r = std::move(done_[seq]);
+        done_.erase(seq);
+        if (r.first != DCN_OK) throw Error(r.first, r.second);
+    }
+    // the six counters summed over every context (ProcessingStats merge, local_filter.rs:388-396); call once
+    // everything submitted has been waited for
+    ProcessingStats stats() {
+        std::vector<dcn_ctx *> ctxs;
+        for (auto &w : workers_) ctxs.push_back(w->ctx);
+        std::array<uint64_t, DCN_N_STATS> c{};
+        check(dcn_stats_allreduce(ctxs.data(), static_cast<int>(ctxs.size()), c.data()));
+        ProcessingStats s;
+        s.total_seqs = c[DCN_STAT_TOTAL_SEQS];
+        s.filtered_seqs = c[DCN_STAT_FILTERED_SEQS];
+        s.total_bp = c[DCN_STAT_TOTAL_BP];
+        s.output_bp = c[DCN_STAT_OUTPUT_BP];
+        s.filtered_bp = c[DCN_STAT_FILTERED_BP];
+        s.output_seq_counter = c[DCN_STAT_OUTPUT_SEQ_COUNTER];
+        return s;
+    }
+
+  private:
+    struct Worker {
+        dcn_ctx *ctx = nullptr;
+        std::thread thread;
+        std::deque<std::pair<uint64_t, Job>> queue;
+    };
+    void finish(uint64_t seq, int rc) {
+        std::string msg = rc == DCN_OK ? std::string() : std::string("deacon_hip error ") + std::to_string(rc) + ": " + dcn_last_error();
+        std::lock_guard<std::mutex> l(m_);
+        done_[seq] = {rc, std::move(msg)};
+        cv_.notify_all();
+    }
+    void work(Worker &w) {
+        dcn_params p;
+        p.abs_threshold = config_.abs_threshold;
+        p.rel_threshold = config_.rel_threshold;
+        p.prefix_length = config_.prefix_length;
+        p.deplete = config_.deplete ? 1u : 0u;
+        p.reserved = 0;
+        std::deque<std::pair<uint64_t, uint64_t>> flying;  // (sequence number, ticket), oldest first
+        for (;;) {
+            std::pair<uint64_t, Job> job;
+            bool have = false;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                // with a batch in flight do not sleep on an empty queue: go and collect it
+                cv_.wait(l, [&] { return stop_ || !w.queue.empty() || !flying.empty(); });
+                if (!w.queue.empty() && flying.size() < 2) {
+                    job = w.queue.front();
+                    w.queue.pop_front();
+                    have = true;
+                    cv_.notify_all();
+                } else if (flying.empty() && stop_) {
+                    return;
+                }
+            }
+            if (have) {
+                uint64_t ticket = 0;
+                int rc = dcn_filter_batch_submit(w.ctx, job.second.bases, job.second.offsets, job.second.unit_id,
+                                                 job.second.n_reads, &p, job.second.keep, job.second.hits,
+                                                 job.second.total, &ticket);
+                if (rc != DCN_OK) finish(job.first, rc);
+                else flying.emplace_back(job.first, ticket);
+                if (flying.size() < 2) continue;  // look for a second batch before blocking on the first
+            }
+            if (!flying.empty()) {
+                auto f = flying.front();
+                flying.pop_front();
+                finish(f.first, dcn_filter_batch_wait(w.ctx, f.second));
+            }
+        }
+    }
+
+    FilterConfig config_;
+    std::size_t queue_depth_;
+    std::vector<Index> replicas_;
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::map<uint64_t, std::pair<int, std::string>> done_;
+    uint64_t next_seq_ = 0;
+    bool stop_ = false;
 };
 
 // filter_common.rs:211-310 for one read: (minimizer hashes, positions) after the ACGT filter

@@ -1,10 +1,11 @@
 // Drives the C++ host layer (include/deacon_hip.hpp) the way the reference's Rust callers drive their filter:
 // build/load an index, create a FilterProcessor, call should_keep_sequence / should_keep_pair / the batch seam.
-// usage: host_layer_test <case file> ; prints one line per result for tests/test_cpp_host.py to compare with the
+// usage: host_layer_test <case file> [devices] ; prints one line per result for tests/test_cpp_host.py to compare with the
 // oracle.  Exit code 3 = the library reported an error (printed on stderr), e.g. no GPU.
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -69,6 +70,58 @@ int main(int argc, char **argv) {
             // server seam: the first read's hashes as one unit
             auto sk = deacon::unpaired_should_keep(proc, {h}, abs_t, rel_t, deplete != 0);
             std::printf("hashes %d %zu %zu\n", std::get<0>(sk[0]) ? 1 : 0, std::get<1>(sk[0]), std::get<2>(sk[0]));
+        }
+        // in-process multi-GPU driver: argv[2] = device list ("0,0" = two contexts on GPU 0); the reads are cut into
+        // batches of whole units, dealt round-robin, merged in sequence order
+        if (argc > 2) {
+            std::vector<int> devices;
+            std::stringstream ss(argv[2]);
+            for (std::string tok; std::getline(ss, tok, ',');) devices.push_back(std::stoi(tok));
+            deacon::MultiGpuFilter multi(index, devices, cfg);
+            const std::size_t per = paired ? 2 : 1, batch_reads = 64 * per;
+            struct Owned {
+                std::vector<uint8_t> bases, keep;
+                std::vector<uint64_t> offsets;
+                std::vector<uint32_t> unit_id, hits, total;
+            };
+            std::vector<std::unique_ptr<Owned>> owned;
+            std::vector<uint64_t> seqs;
+            for (std::size_t r0 = 0; r0 < reads.size(); r0 += batch_reads) {
+                std::size_t r1 = std::min(reads.size(), r0 + batch_reads);
+                owned.emplace_back(new Owned());
+                Owned &o = *owned.back();
+                o.offsets.push_back(0);
+                for (std::size_t r = r0; r < r1; ++r) {
+                    o.bases.insert(o.bases.end(), reads[r].begin(), reads[r].end());
+                    o.offsets.push_back(o.bases.size());
+                    if (paired) o.unit_id.push_back((uint32_t)((r - r0) / 2));
+                }
+                std::size_t nu = paired ? (r1 - r0 + 1) / 2 : r1 - r0;
+                o.keep.assign(nu, 0);
+                o.hits.assign(nu, 0);
+                o.total.assign(nu, 0);
+                deacon::MultiGpuFilter::Job job;
+                job.bases = o.bases.data();
+                job.offsets = o.offsets.data();
+                job.unit_id = paired ? o.unit_id.data() : nullptr;
+                job.n_reads = (uint32_t)(r1 - r0);
+                job.keep = o.keep.data();
+                job.hits = o.hits.data();
+                job.total = o.total.data();
+                seqs.push_back(multi.submit(job));
+            }
+            std::printf("multi %zu", multi.workers());
+            for (std::size_t i = 0; i < seqs.size(); ++i) {
+                multi.wait(seqs[i]);  // ordered merge: by batch sequence number
+                for (std::size_t u = 0; u < owned[i]->keep.size(); ++u)
+                    std::printf(" %d:%u:%u", owned[i]->keep[u], owned[i]->hits[u], owned[i]->total[u]);
+            }
+            std::printf("\n");
+            auto ms = multi.stats();
+            std::printf("multistats %llu %llu %llu %llu %llu %llu\n", (unsigned long long)ms.total_seqs,
+                        (unsigned long long)ms.filtered_seqs, (unsigned long long)ms.total_bp,
+                        (unsigned long long)ms.output_bp, (unsigned long long)ms.filtered_bp,
+                        (unsigned long long)ms.output_seq_counter);
         }
     } catch (const deacon::Error &e) {
         std::fprintf(stderr, "deacon::Error %d: %s\n", e.code(), e.what());

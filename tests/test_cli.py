@@ -369,6 +369,48 @@ def test_batches_cut_into_several_calls(tmp_path, oracle, paired, monkeypatch):
 
 
 @gpu
+@pytest.mark.parametrize("paired", [False, True])
+def test_multi_gpu_driver_gives_the_single_context_output(tmp_path, oracle, paired, monkeypatch):
+    """`--devices 0,0,0` = three pipeline contexts on the one GPU of the box (index replicated device to device,
+    calls dealt round-robin, two in flight per context, merged by sequence number): byte-identical output to the
+    single-context run, same summary counters.  Mixed long + short reads, gzip in (BASELINE configs[4]'s stream)."""
+    rng = np.random.default_rng(58)
+    genome = random_reads(rng, 1, 80_000, 80_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    oidx = oracle.Index.build([genome])
+    reads = []
+    for i in range(4000):
+        ln = int(rng.integers(30, 250)) if i % 50 else int(rng.integers(3_000, 30_000))
+        s = int(rng.integers(0, len(genome) - ln))
+        reads.append(mutate(rng, genome[s:s + ln], 0.03) if i % 2 else random_reads(rng, 1, ln, ln, p_n=0.002)[0])
+    b, o = oracle.concat_reads(reads)
+    monkeypatch.setenv("DCN_CLI_MAX_BATCH_READS", "500")  # many calls, so that every context gets work
+    outs = {}
+    for name, extra in (("one", []), ("three", ["--devices", "0,0,0"]), ("gpus1", ["--gpus", "1"])):
+        summ = tmp_path / f"{name}.json"
+        if paired:
+            for m in (1, 2):
+                with gzip.open(tmp_path / f"r{m}.fq.gz", "wb") as f:
+                    f.write("".join(f"@r{i}/{m}\n{reads[2 * i + m - 1].decode()}\n+\n{'I' * len(reads[2 * i + m - 1])}\n"
+                                    for i in range(2000)).encode())
+            p = run("filter", "-d", idx, tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz", "-s", summ, *extra)
+        else:
+            with gzip.open(tmp_path / "r.fq.gz", "wb") as f:
+                f.write("".join(f"@r{i}\n{r.decode()}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads)).encode())
+            p = run("filter", "-d", idx, tmp_path / "r.fq.gz", "-s", summ, *extra)
+        sj = json.loads(summ.read_text())
+        outs[name] = (p.stdout, {k_: sj[k_] for k_ in ("seqs_in", "seqs_out", "bp_in", "bp_out", "seqs_removed", "bp_removed")})
+    assert outs["three"] == outs["one"] == outs["gpus1"]
+    uid = (np.arange(4000) // 2).astype(np.uint32) if paired else None
+    keep, _, _ = oracle.filter_batch(oidx, b, o, uid, deplete=True)
+    ids = [l[1:] for l in outs["three"][0].decode().split("\n")[0::4] if l]
+    want = [f"r{i}/{m}" for i in range(2000) if keep[i] for m in (1, 2)] if paired else [f"r{i}" for i in range(4000) if keep[i]]
+    assert ids == want
+    assert b"no such HIP device" in run("filter", idx, tmp_path / ("r1.fq.gz" if paired else "r.fq.gz"), "--devices", "0,7",
+                                        check=False).stderr
+
+
+@gpu
 def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
     """The mmap parser cuts the file at record boundaries it has to find from the middle of nowhere: qualities that
     start with '@' or '+', ids containing '+', Windows line ends and a missing final newline must not move a cut."""

@@ -17,7 +17,7 @@ def driver(tmp_path_factory, dcn):
     libdir = os.path.dirname(dcn._native.LIB_PATH)
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "host_layer_test.cpp"), "-o", str(out),
-                           "-L", libdir, "-ldeacon_hip", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+                           "-L", libdir, "-ldeacon_hip", "-lpthread", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
     return str(out)
 
 
@@ -59,7 +59,7 @@ def test_cpp_layer_matches_oracle(driver, oracle, tmp_path, paired, deplete):
     reads[7] = b""
     case = tmp_path / "case.txt"
     write_case(case, 31, 15, 2, 0.01, 0, deplete, paired, oidx.keys(), reads)
-    p = subprocess.run([driver, str(case)], capture_output=True, text=True, check=True)
+    p = subprocess.run([driver, str(case), "0,0,0"], capture_output=True, text=True, check=True)
     lines = p.stdout.strip().split("\n")
     assert lines[0] == f"header 31 15 {len(oidx)}"
     uid = (np.arange(len(reads)) // 2).astype(np.uint32) if paired else None
@@ -76,6 +76,15 @@ def test_cpp_layer_matches_oracle(driver, oracle, tmp_path, paired, deplete):
     st = [int(x) for x in next(l for l in lines if l.startswith("stats ")).split()[1:]]
     assert st == [len(reads), int(ucnt[~keep].sum()), int(lens.sum()), int(ulen[keep].sum()),
                   int(ulen[~keep].sum()), int(ucnt[keep].sum())]
+    # deacon::MultiGpuFilter over three contexts on GPU 0 (index cloned device to device, batches of 64 units dealt
+    # round-robin, merged by sequence number): identical to the single-context run, counters summed
+    multi = next(l for l in lines if l.startswith("multi ")).split()[1:]
+    assert multi[0] == "3"
+    # batches hold whole units and 128 reads (64 units when paired), so pairing is the same as in the one-batch run
+    assert [tuple(int(x) for x in m.split(":")) for m in multi[1:]] == \
+        list(zip(keep.astype(int).tolist(), hits.tolist(), total.tolist()))
+    mst = [int(x) for x in next(l for l in lines if l.startswith("multistats ")).split()[1:]]
+    assert mst == st
     single = [int(x) for x in next(l for l in lines if l.startswith("single ")).split()[1:]]
     assert single == [int(keep[0]), int(hits[0]), int(total[0])]
     wh, wp = oracle.minimizer_hashes_and_positions(reads[0], 31, 15)

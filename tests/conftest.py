@@ -83,3 +83,31 @@ _COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
 
 def revcomp(seq):
     return bytes(seq).translate(_COMP)[::-1]
+
+
+# ---- synthetic index remainder with decidable membership (also used by bench.py) ----------------------------------
+_M1, _M2 = 0xBF58476D1CE4E5B9, 0x94D049BB133111EB
+
+
+def mix64(i):
+    """splitmix64's finalizer on a numpy uint64 array: a bijection on u64"""
+    z = np.asarray(i, dtype=np.uint64).copy()
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(_M1)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(_M2)
+        return z ^ (z >> np.uint64(31))
+
+
+def unmix64(h):
+    """its inverse: h is in {mix64(i) : 1 <= i <= n} iff 1 <= unmix64(h) <= n"""
+    h = np.asarray(h, dtype=np.uint64)
+
+    def inv_xs(y, s):
+        x = y.copy()
+        for _ in range(64 // s + 1):
+            x = y ^ (x >> np.uint64(s))
+        return x
+    with np.errstate(over="ignore"):
+        z = inv_xs(h, 31) * np.uint64(pow(_M2, -1, 1 << 64))
+        z = inv_xs(z, 27) * np.uint64(pow(_M1, -1, 1 << 64))
+        return inv_xs(z, 30)

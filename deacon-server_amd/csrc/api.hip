@@ -371,7 +371,7 @@ struct dcn_ctx {
     // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
     // units whose hits do not fit the LDS set of the distinct pass (4 slots per record of capacity)
     uint64_t *d_rec_hash = nullptr;
-    uint32_t *d_tile_hits = nullptr;
+    uint32_t *d_tile_hits = nullptr, *d_pending = nullptr;
     uint64_t rec_capacity = 0;
     uint64_t *d_set_slots = nullptr;
     dcn_status *d_status = nullptr;
@@ -455,7 +455,7 @@ void free_ctx(dcn_ctx *c) {
     void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask,
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
                    c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
-                   c->d_set_off, c->d_tile_hits, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
+                   c->d_set_off, c->d_tile_hits, c->d_pending, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
     for (void *p : dev)
         if (p) hipFree(p);
@@ -613,6 +613,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     sa.g_zero = g_zero;
     sa.rec_hash = c->d_rec_hash;
     sa.tile_hits = c->d_tile_hits;
+    sa.pending = c->d_pending;
     sa.status = c->d_status;
     uint64_t tile_bound = (uint64_t)n_reads + (v.b1 - v.b0) / c->tile_windows + 1;
     if (tile_bound > c->max_tiles) tile_bound = c->max_tiles;
@@ -626,6 +627,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     da.unit_tile_count = c->d_unit_tile_count;
     da.unit_state = c->d_unit_state;
     da.tile_hits = c->d_tile_hits;
+    da.pending = c->d_pending;
     da.rec_hash = c->d_rec_hash;
     da.g_hitcnt = g_hitcnt;
     da.g_distinct = g_distinct;
@@ -678,7 +680,7 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     DCN_HIP(hipMemcpy(c->h_report, c->d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost));
     if (c->h_report->overflow) {
         const uint64_t need = c->h_report->need;
-        DCN_HIP(hipMemset(c->d_report, 0, offsetof(dcn_batch_report, stats))); // re-arm
+        DCN_HIP(hipMemsetAsync(c->d_report, 0, offsetof(dcn_batch_report, stats), c->stream)); // re-arm, ordered before the next batch
         if (needed_records) *needed_records = need;
         return overflow_error(c, need);
     }
@@ -998,6 +1000,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_caps, MR, "caps");
     A(d_set_off, MR + 1, "set_off");
     A(d_tile_hits, mt, "tile_hits");
+    A(d_pending, MR, "pending");
     A(d_rec_hash, max_batch_bases + 64, "rec_hash");
     A(d_status, 1, "status");
     A(d_report, 1, "report");
@@ -1017,7 +1020,11 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     if (hipMemset(c->d_packed, 0, packed_words(max_batch_bases) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->d_invmask, 0, mask_words(max_batch_bases) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->d_status, 0, sizeof(dcn_status)) != hipSuccess ||
-        hipMemset(c->d_report, 0, sizeof(dcn_batch_report)) != hipSuccess)
+        hipMemset(c->d_report, 0, sizeof(dcn_batch_report)) != hipSuccess ||
+        // hipMemset runs on the null stream and does not wait for the host; the context's streams are non-blocking
+        // and do not wait for the null stream: without this, the first batch's copies into the packed stream can
+        // be overtaken by the memset above (seen as an all-'A' first chunk, once in a few hundred runs)
+        hipDeviceSynchronize() != hipSuccess)
         return fail(dcn_fail(DCN_ERR_HIP, "hipMemset failed"));
     *out = c;
     return DCN_OK;
@@ -1126,6 +1133,7 @@ int alloc_slot(dcn_ctx *c, int si) {
         DCN_TRY(dev_alloc(&sl.d_total, MR, "slot total"));
         DCN_HIP(hipMemset(sl.d_packed, 0, packed_words(c->max_bases) * sizeof(uint32_t)));
         DCN_HIP(hipMemset(sl.d_invmask, 0, mask_words(c->max_bases) * sizeof(uint32_t)));
+        DCN_HIP(hipDeviceSynchronize()); // the null-stream memsets must not overtake this slot's first copies
     }
     DCN_TRY(dev_alloc(&sl.d_report, 1, "slot report"));
     DCN_HIP(hipHostMalloc((void **)&sl.h_report, sizeof(dcn_batch_report), hipHostMallocDefault));
@@ -1517,7 +1525,8 @@ extern "C" int dcn_ctx_reset_stats(dcn_ctx *ctx) {
     if (!ctx) return dcn_fail(DCN_ERR_ARG, "ctx is NULL");
     DCN_HIP(hipSetDevice(ctx->device));
     DCN_HIP(hipStreamSynchronize(ctx->stream));
-    DCN_HIP(hipMemset(ctx->d_report->stats, 0, sizeof(unsigned long long) * DCN_N_STATS));
+    DCN_HIP(hipMemsetAsync(ctx->d_report->stats, 0, sizeof(unsigned long long) * DCN_N_STATS, ctx->stream));
+    DCN_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < DCN_N_STATS; ++i) ctx->host_stats[i] = 0;
     return DCN_OK;
 }
@@ -1702,6 +1711,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         pa.tile_hits = c->d_tile_hits;
         pa.unit_tile_first = c->d_unit_tile_first;
         pa.unit_tile_count = c->d_unit_tile_count;
+        pa.pending = c->d_pending;
         pa.unit_state = c->d_unit_state;
         pa.g_total = g_total;
         pa.g_hitcnt = g_hitcnt;
@@ -1716,6 +1726,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         da.unit_tile_count = c->d_unit_tile_count;
         da.unit_state = c->d_unit_state;
         da.tile_hits = c->d_tile_hits;
+        da.pending = c->d_pending;
         da.rec_hash = d_hashes;
         da.g_hitcnt = g_hitcnt;
         da.g_distinct = g_distinct;

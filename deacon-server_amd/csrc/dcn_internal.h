@@ -95,8 +95,8 @@ struct dcn_status {
     uint32_t n_tiles;
     uint32_t any_records;          // the scan wrote a hit into some tile's run: the distinct pass has work
     uint32_t any_big;              // some unit has more hits than the LDS set holds: the global-set kernels have work
+    uint32_t n_pending;            // units enrolled for the distinct pass (scan.hip)
     uint32_t any_newline;          // the pack kernel saw a '\n' byte: only then does planning probe read ends
-    uint32_t reserved;
     unsigned long long set_cursor; // distinct pass: slots handed out to the global per-unit hash sets
 };
 
@@ -134,10 +134,11 @@ struct dcn_scan_args {
     uint8_t *unit_state; // 1 = resolved by the scan kernel
     // outputs for units spanning several waves (or too large for the in-wave hit ring)
     uint32_t *g_total;   // per unit, atomically accumulated
-    uint32_t *g_hitcnt;  // per unit: hit count, only maintained for units whose tiles are not contiguous
+    uint32_t *g_hitcnt;  // per unit: hits written to its runs (one atomicAdd per wave holding tiles of the unit)
     uint32_t *g_zero;    // per unit: the zero hash was a hit
-    uint64_t *rec_hash;  // one slot per base of the batch stream: tile t's hits fill [scan_start + carry, ...) in order
-    uint32_t *tile_hits; // per tile: length of that run
+    uint64_t *rec_hash;  // one slot per base of the batch stream; a run starts at scan_start + carry of its first tile
+    uint32_t *tile_hits; // per tile: length of the run that starts at this tile (0: none)
+    uint32_t *pending;   // units the scan did not finish, in no particular order (status->n_pending of them)
     dcn_status *status;
     // dump mode (dcn_minimizer_hashes_batch): per emitted minimizer
     uint64_t *dump_hash;

@@ -31,9 +31,10 @@ struct dcn_distinct_args {
     const uint32_t *unit_tile_first; // n_units
     const uint32_t *unit_tile_count; // n_units; 0xFFFFFFFF: not contiguous (hit count in g_hitcnt, always a global set)
     const uint8_t *unit_state;       // 1 = finished by the scan kernel
-    const uint32_t *tile_hits;       // per tile: length of its run in rec_hash
+    const uint32_t *tile_hits;       // per tile: length of the run that starts at it
     const uint64_t *rec_hash;        // runs of hit hashes, 0 = no entry
-    const uint32_t *g_hitcnt;
+    const uint32_t *pending;         // work list: status->n_pending units
+    const uint32_t *g_hitcnt;        // per unit: total run length
     uint32_t *g_distinct;
     uint32_t *set_off; // n_units: first slot of a unit's global set (only for units with caps != 0)
     uint32_t *caps;    // n_units: global set size (power of two), 0 = none (counted in LDS, or no hits)
@@ -67,7 +68,7 @@ struct dcn_probe_hashes_args {
     // one pseudo-tile per unit, so that the distinct pass of the scan path serves this seam too
     dcn_tile *tiles;
     uint32_t *n_tiles;
-    uint32_t *tile_hits, *unit_tile_first, *unit_tile_count;
+    uint32_t *tile_hits, *unit_tile_first, *unit_tile_count, *pending;
     uint8_t *unit_state;
     uint32_t *g_total, *g_hitcnt, *g_distinct, *g_zero;
     dcn_status *status;

@@ -145,6 +145,7 @@ int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n) {
         idx->n_keys = h_new;
         idx->has_zero = h_zero != 0;
     }
+    if (rc == DCN_OK && hipDeviceSynchronize() != hipSuccess) rc = dcn_fail(DCN_ERR_HIP, "table build: device synchronize failed");
     hipFree(d_keys);
     hipFree(d_new);
     hipFree(d_zero);
@@ -307,6 +308,9 @@ int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity) {
     idx->n_groups = groups;
     DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     DCN_HIP(hipMemset(idx->d_slots, 0, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    // the memset runs on the null stream without waiting for the host, and the callers' streams are non-blocking
+    // (they do not wait for the null stream): the table must be clear before anyone inserts or probes
+    DCN_HIP(hipDeviceSynchronize());
     idx->n_keys = 0;
     idx->has_zero = false;
     return DCN_OK;

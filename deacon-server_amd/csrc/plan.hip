@@ -148,16 +148,17 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
 
 // ---- exact distinct-hit count of the units the scan kernel did not finish ------------------------------------
 // (long reads, pairs cut by a wave boundary, units with more hits than the in-wave ring holds.)  The scan kernel left
-// every such unit's hits as per-tile runs in the record array (scan.hip): tile t's run starts at slot
-// scan_start + carry and holds tile_hits[t] hashes, 0 standing for "no entry" (a zero-hash hit is flagged in g_zero).
+// every such unit's hits as runs in the record array (scan.hip): the run of (wave, unit) starts at slot
+// scan_start + carry of the unit's first tile in that wave, tile_hits[that tile] hashes long (every other tile of the
+// unit has tile_hits 0); a 0 entry stands for "nothing" (a zero-hash hit is flagged in g_zero).  g_hitcnt[u] is the
+// unit's total run length, status->n_pending / pending[] the work list.
 //
-// Pass A, one wave per pending unit: sum the unit's run lengths; up to DCN_LDS_SET_MAX hits are deduplicated in an
-// LDS hash set right here -- no global atomics at all, which is where the old (unit, hash) CAS pass spent 0.64 ms per
-// 600 Mbp of long reads.  A larger unit (a read of several hundred kbp from the indexed genome) gets a region of the
-// global set scratch instead, so that pass B can spread its runs over the whole chip.
-// Every kernel here returns at once when the scan wrote no run (batches of short single reads).
-constexpr uint32_t DCN_LDS_SET_SLOTS = 4096; // 32 KB
-constexpr uint32_t DCN_LDS_SET_MAX = 2800;   // hits deduplicated in LDS (load <= 0.68)
+// Pass A, one wave per enrolled unit: up to DCN_LDS_SET_MAX hits are deduplicated in an LDS hash set right here -- no
+// global atomics at all, which is where the old (unit, hash) CAS pass spent 0.64 ms per 600 Mbp of long reads.  A
+// larger unit (a long read from the indexed genome) gets a region of the global set scratch instead, so that pass B
+// can spread its runs over the whole chip.
+constexpr uint32_t DCN_LDS_SET_SLOTS = 2048; // 16 KB: ten waves per CU
+constexpr uint32_t DCN_LDS_SET_MAX = 1400;   // hits deduplicated in LDS (load <= 0.68)
 
 __device__ inline uint32_t set_slot_of(uint64_t h, uint32_t cap) {
     uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
@@ -166,65 +167,62 @@ __device__ inline uint32_t set_slot_of(uint64_t h, uint32_t cap) {
 
 __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) {
     __shared__ unsigned long long set[DCN_LDS_SET_SLOTS];
-    if (a.status->any_records == 0) return;
+    const uint32_t NP = a.status->n_pending;
     const uint32_t lane = threadIdx.x;
-    const uint32_t NT = *a.n_tiles;
-    for (uint32_t ubase = blockIdx.x * 64; ubase < a.n_units; ubase += gridDim.x * 64) {
-        const uint32_t mine = ubase + lane;
-        unsigned long long pending = __ballot(mine < a.n_units && a.unit_state[mine] == 0);
-        while (pending) {
-            const uint32_t u = ubase + (uint32_t)__ffsll((long long)pending) - 1;
-            pending &= pending - 1;
-            const uint32_t first = a.unit_tile_first[u], count = a.unit_tile_count[u];
-            const bool contiguous = count != 0xFFFFFFFFu;
-            uint32_t H = 0;
-            if (contiguous) {
-                for (uint32_t i = lane; i < count; i += 64) H += first + i < NT ? a.tile_hits[first + i] : 0u;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) H += __shfl_xor(H, d, 64);
-            } else {
-                H = a.g_hitcnt[u];
+    // the next unit's descriptor is fetched while this one is counted
+    uint32_t nu = 0, nfirst = 0, ncount = 0, nH = 0;
+    auto fetch = [&](uint32_t i) {
+        if (i < NP) {
+            nu = a.pending[i];
+            nfirst = a.unit_tile_first[nu];
+            ncount = a.unit_tile_count[nu];
+            nH = a.g_hitcnt[nu];
+        }
+    };
+    fetch(blockIdx.x);
+    for (uint32_t i = blockIdx.x; i < NP; i += gridDim.x) {
+        const uint32_t u = nu, first = nfirst, count = ncount, H = nH;
+        fetch(i + gridDim.x);
+        if (H == 0) {
+            if (lane == 0) a.caps[u] = 0;
+            continue;
+        }
+        if (count == 0xFFFFFFFFu || H > DCN_LDS_SET_MAX) {
+            // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor
+            if (lane == 0) {
+                uint32_t cap = 64;
+                while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
+                a.set_off[u] = (uint32_t)atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
+                a.caps[u] = cap;
+                a.status->any_big = 1;
             }
-            if (H == 0) {
-                if (lane == 0) a.caps[u] = 0;
-                continue;
+            continue;
+        }
+        uint32_t cap = 64;
+        while (cap < 2u * H) cap <<= 1;
+        if (cap > DCN_LDS_SET_SLOTS) cap = DCN_LDS_SET_SLOTS;
+        for (uint32_t q = lane; q < cap; q += 64) set[q] = 0;
+        __syncthreads();
+        uint32_t distinct = 0;
+        for (uint32_t t0 = 0; t0 < count; t0 += 64) {
+            const uint32_t t = t0 + lane;
+            const uint32_t n = t < count ? a.tile_hits[first + t] : 0u;
+            uint64_t slot0 = 0;
+            if (n) {
+                const dcn_tile tl = a.tiles[first + t];
+                slot0 = tl.scan_start + (tl.flags & 1u);
             }
-            if (!contiguous || H > DCN_LDS_SET_MAX) {
-                // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor
-                if (lane == 0) {
-                    uint32_t cap = 64;
-                    while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
-                    a.set_off[u] = (uint32_t)atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
-                    a.caps[u] = cap;
-                    a.status->any_big = 1;
-                }
-                continue;
-            }
-            uint32_t cap = 64;
-            while (cap < 2u * H) cap <<= 1;
-            if (cap > DCN_LDS_SET_SLOTS) cap = DCN_LDS_SET_SLOTS;
-            for (uint32_t i = lane; i < cap; i += 64) set[i] = 0;
-            __syncthreads();
-            uint32_t distinct = 0;
-            // four tiles per step, 16 lanes each: their loads are in flight together
-            const uint32_t grp = lane >> 4, sub = lane & 15;
-            for (uint32_t t0 = 0; t0 < count; t0 += 4) {
-                const uint32_t ti = t0 + grp;
-                uint32_t n = 0;
-                uint64_t slot0 = 0;
-                if (ti < count) {
-                    n = a.tile_hits[first + ti];
-                    const dcn_tile tl = a.tiles[first + ti];
-                    slot0 = tl.scan_start + (tl.flags & 1u);
-                }
-                uint32_t nmax = n;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor(nmax, d, 64));
-                for (uint32_t j = sub; j < nmax + sub; j += 16) { // wave-uniform trip count
-                    const bool act = j < n;
-                    const uint64_t h = act ? a.rec_hash[slot0 + j] : 0ull;
+            unsigned long long runs = __ballot(n != 0);
+            while (runs) { // one or two per unit: a run per wave that held tiles of it
+                const int r = __ffsll((long long)runs) - 1;
+                runs &= runs - 1;
+                const uint32_t rn = __shfl(n, r, 64);
+                const uint64_t rs = (uint64_t)__shfl((long long)slot0, r, 64);
+                for (uint32_t j0 = 0; j0 < rn; j0 += 64) {
+                    const uint32_t j = j0 + lane;
+                    const uint64_t h = j < rn ? a.rec_hash[rs + j] : 0ull;
                     bool fresh = false;
-                    if (act && h != 0) {
+                    if (h != 0) {
                         uint32_t sl = set_slot_of(h, cap);
                         for (;;) {
                             unsigned long long old = atomicCAS(&set[sl], 0ull, (unsigned long long)h);
@@ -239,11 +237,11 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
                     distinct += (uint32_t)__popcll(__ballot(fresh));
                 }
             }
-            __syncthreads();
-            if (lane == 0) {
-                a.g_distinct[u] = distinct; // the zero-hash flag is added by the finish kernel
-                a.caps[u] = 0;
-            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            a.g_distinct[u] = distinct; // the zero-hash flag is added by the finish kernel
+            a.caps[u] = 0;
         }
     }
 }
@@ -384,6 +382,7 @@ __global__ __launch_bounds__(256) void hash_units_kernel(dcn_probe_hashes_args a
     if (u == 0) {
         *a.n_tiles = a.n_units;
         a.status->any_records = 1;
+        a.status->n_pending = a.n_units;
     }
     if (u >= a.n_units) return;
     const uint64_t n = a.hash_offsets[u + 1] - a.hash_offsets[u];
@@ -398,8 +397,9 @@ __global__ __launch_bounds__(256) void hash_units_kernel(dcn_probe_hashes_args a
     a.unit_tile_first[u] = u;
     a.unit_tile_count[u] = 1;
     a.unit_state[u] = 0;
+    a.pending[u] = u;
     a.g_total[u] = (uint32_t)n;
-    a.g_hitcnt[u] = 0;
+    a.g_hitcnt[u] = (uint32_t)n;
     a.g_distinct[u] = 0;
     a.g_zero[u] = 0;
 }
@@ -422,8 +422,7 @@ int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream) {
 }
 
 int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream) {
-    uint32_t groups = (a.n_units + 63) / 64;
-    hipLaunchKernelGGL(unit_distinct_kernel, dim3(std::max(1u, std::min(groups, 256u * 20u))), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(unit_distinct_kernel, dim3(std::max(1u, std::min(a.n_units, 256u * 10u))), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_capacity, a.status);
     hipLaunchKernelGGL(big_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());

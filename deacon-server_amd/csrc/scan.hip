@@ -49,11 +49,17 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+constexpr int DCN_LSTRIDE = 42;  // u16 entries per list row: DCN_LCAP + 2, 21 dwords
+static_assert(DCN_LSTRIDE >= DCN_LCAP && (DCN_LSTRIDE / 2) % 2 == 1 && DCN_LSTRIDE % 2 == 0, "odd dword stride");
 constexpr int DCN_RCAP = 256; // LDS ring of the most recent hits; a unit resolved in-wave has <= RCAP-64 items
 
 struct WaveShared {
     uint4 tab[16];                      // {F[in], rotl(F[in^2],k-1), rotl(F[out],k), rotr(F[out^2],1)} at in | out<<2
-    uint16_t list[DCN_LCAP][DCN_WAVE];  // per-lane emitted positions (relative to the tile's scan start)
+    // per-lane emitted positions (relative to the tile's scan start), one row per lane.  The row stride is an odd
+    // number of dwords: phase A's store of entry cnt by every lane, and phase B's read of consecutive entries of one
+    // lane by consecutive lanes, both spread over the banks (rows of 64 lanes x u16 put a lane's whole list on one
+    // bank: phase B then read it 13-way conflicted on average)
+    uint16_t list[DCN_WAVE][DCN_LSTRIDE];
     uint64_t ring_hash[DCN_RCAP];
     uint32_t total[DCN_WAVE];           // per unit slot: emitted minimizers minus those failing the ACGT test
     uint32_t hits[DCN_WAVE];            // per unit slot: distinct hits
@@ -61,7 +67,8 @@ struct WaveShared {
     uint32_t hraw[DCN_WAVE];            // per unit slot: hits pushed through the ring so far
     uint32_t unit_of[DCN_WAVE];         // unit slot -> global unit id
     uint16_t start[DCN_WAVE + 2];       // exclusive prefix of the per-lane list lengths
-    uint32_t thits[DCN_WAVE];           // per lane (tile): hits written to the tile's run of the record array so far
+    uint32_t uhits[DCN_WAVE];           // per unit slot: hits written to the unit's run of the record array so far
+    uint8_t head_of[DCN_WAVE];          // unit slot -> its first lane in this wave
     uint8_t local[DCN_WAVE];            // unit slot has all its tiles in this wave
     uint8_t lok[DCN_WAVE];              // unit slot is being resolved inside this wave
     uint8_t ncont[DCN_WAVE];            // unit slot's tiles are not contiguous (a unit cut by a planning block)
@@ -127,14 +134,17 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     sh.items[lane] = 0;
     sh.hraw[lane] = 0;
     sh.lok[lane] = 0;
-    sh.thits[lane] = 0;
+    sh.uhits[lane] = 0;
+    bool unit_starts_here = false; // this lane holds the first tile of its unit (the wave that enrols the unit below)
     if (head) {
         sh.unit_of[uslot] = t.unit;
+        sh.head_of[uslot] = (uint8_t)lane;
         bool loc = false, nc = false;
         if (!DUMP) {
             uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
             nc = count == 0xFFFFFFFFu;
             loc = !nc && first >= wave_first && first + count <= wave_first + DCN_WAVE;
+            unit_starts_here = have_tile && first == tile_idx;
         }
         sh.local[uslot] = loc ? 1 : 0;
         sh.ncont[uslot] = nc ? 1 : 0;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 uint32_t e = E + u * DCN_WAVE + lane;
                 idx[u] = act[u] ? e - sh.start[lo[u]] : 0;
                 uint32_t o_skip = __shfl(skip0, lo[u], 64);
-                rel[u] = sh.list[idx[u] + o_skip][lo[u]];
+                rel[u] = sh.list[lo[u]][idx[u] + o_skip];
                 long long o_s = __shfl((long long)s, lo[u], 64);
                 o_uslot[u] = __shfl(uslot, lo[u], 64);
                 p[u] = (uint64_t)(o_s + rel[u]);
@@ -361,12 +371,13 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     n_ring += nh;
                     __syncthreads();
                 }
-                // hits of every other unit: appended to the owner TILE's run of the record array.  Tile t owns the
-                // slots [scan_start + carry, + n_windows) (one per window, so a run can never overflow and runs of
-                // different tiles never overlap); its hits fill the run from the front in item order.  No global
-                // atomics: the running count of a tile lives in LDS, and since items are in flat order the hits of
-                // one tile sit in adjacent lanes of a round.  plan.hip's distinct pass reads the runs back.
-                // A zero hash (0 marks an empty set slot there) is flagged per unit instead of recorded.
+                // hits of every other unit: appended to the unit's RUN in the record array.  The array has one slot per
+                // base of the batch stream; the run of (this wave, unit) starts at the slot of the first window of the
+                // unit's first tile in this wave and can take one entry per window of the unit's tiles here -- it can
+                // neither overflow nor reach another run.  Its hits fill it from the front in item order.  No global
+                // atomics: the running length lives in LDS, and since items are in flat order the hits of one unit
+                // sit in adjacent lanes of a round.  plan.hip's distinct pass reads the runs back (coalesced).
+                // A zero hash (0 marks an empty set slot there) is flagged per unit instead of counted there.
                 {
                     const bool rec = hit[u] && !lok;
                     const unsigned long long rb = __ballot(rec);
@@ -374,20 +385,21 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         const unsigned long long lt = (1ull << lane) - 1;
                         const unsigned long long below = rb & lt;
                         const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
-                        const uint32_t prev_owner = __shfl(lo[u], prev_lane, 64);
-                        const bool run_head = rec && (below == 0 || prev_owner != lo[u]);
+                        const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
+                        const bool run_head = rec && (below == 0 || prev_us != o_uslot[u]);
                         const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
                         const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
                         const uint32_t rank = (uint32_t)__popcll(below) - (uint32_t)__popcll(rb & ((1ull << head_lane) - 1));
-                        const long long o_s = __shfl((long long)s, lo[u], 64);
-                        const uint32_t o_carry = __shfl(carry, lo[u], 64);
+                        const uint32_t unit_lane = sh.head_of[o_uslot[u]];
+                        const long long o_s = __shfl((long long)s, unit_lane, 64);
+                        const uint32_t o_carry = __shfl(carry, unit_lane, 64);
                         any_rec = true;
                         if (rec) {
-                            const uint32_t before = sh.thits[lo[u]];
+                            const uint32_t before = sh.uhits[o_uslot[u]];
                             a.rec_hash[(uint64_t)o_s + o_carry + before + rank] = hash[u];
                             if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
-                        if (rec) atomicAdd(&sh.thits[lo[u]], 1u); // after every lane of the run has read the old count
+                        if (rec) atomicAdd(&sh.uhits[o_uslot[u]], 1u); // after every lane of the run has read the old length
                     }
                 }
             }
@@ -539,7 +551,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     // FIRST: window 0, always emitted (a carry tile's copy is dropped in phase B);
                     // later blocks: window j-(w-1) >= 1, emitted when in range and different from its predecessor
                     const bool emit = FIRST ? (nwc > 0) : ((j - (w - 1) < nwc) && sel != prev);
-                    if (!(DCN_EXP & 4)) sh.list[cnt][lane] = (uint16_t)sel;
+                    if (!(DCN_EXP & 4)) sh.list[lane][cnt] = (uint16_t)sel;
                     cnt += emit ? 1u : 0u;
                     prev = sel;
                 }
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 const uint32_t i = j - (w - 1); // window index; wraps while j < w-1
                 const bool in_range = i < nwc;  // unsigned compare: false while i is "negative"
                 const bool emit = in_range && sel != prev;
-                sh.list[cnt][lane] = (uint16_t)sel;
+                sh.list[lane][cnt] = (uint16_t)sel;
                 cnt += emit ? 1u : 0u;
                 prev = in_range ? sel : prev;
             }
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 const bool actv = j < cnt_eff && nh < need;
                 if (!__any(actv)) break;
                 uint64_t hash;
-                const uint32_t rel = sh.list[(actv ? j : 0u) + skip0][lane];
+                const uint32_t rel = sh.list[lane][(actv ? j : 0u) + skip0];
                 const bool hit = probe_item((uint64_t)(s + rel), actv, hash);
                 // both lanes of a pair apply the unit's hits in the same order (first mate's, then second mate's)
                 const bool p_hit = __shfl((int)hit, partner, 64) != 0;
@@ -681,7 +693,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     const uint32_t o_skip = __shfl(skip0, lo, 64);
                     const uint32_t o_nh = __shfl(nh, lo, 64);
                     const long long o_s = __shfl((long long)s, lo, 64);
-                    const uint32_t rel = sh.list[idx + o_skip][lo];
+                    const uint32_t rel = sh.list[lo][idx + o_skip];
                     uint64_t hash;
                     const bool hit = probe_item((uint64_t)(o_s + rel), act && o_nh < need, hash);
                     // hand each hit to its owner lane, one at a time (rare for reads that are not from the index)
@@ -709,12 +721,24 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
         return;
     }
 
-    // ---- hit runs of the tiles whose unit is finished by the distinct pass --------------------------------------
+    // ---- units left to the distinct pass: run lengths, hit totals, enrolment ------------------------------------------
     if (any_rec && lane == 0) a.status->any_records = 1;
-    if (have_tile && !sh.lok[uslot]) {
-        const uint32_t th = sh.thits[lane];
-        a.tile_hits[tile_idx] = th;
-        if (th && sh.ncont[uslot]) atomicAdd(&a.g_hitcnt[t.unit], th); // no tile list to sum over: count here
+    {
+        const bool pending = have_tile && !sh.lok[uslot];
+        if (pending) {
+            const uint32_t th = head ? sh.uhits[uslot] : 0u; // the run hangs on the unit's first tile in this wave
+            a.tile_hits[tile_idx] = th;
+            if (th) atomicAdd(&a.g_hitcnt[t.unit], th); // one per (wave, unit)
+        }
+        // the wave holding a unit's first tile puts it on the distinct pass's work list
+        const bool enrol = pending && unit_starts_here;
+        const unsigned long long em = __ballot(enrol);
+        if (em) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&a.status->n_pending, (uint32_t)__popcll(em));
+            base = __shfl(base, 0, 64);
+            if (enrol) a.pending[base + (uint32_t)__popcll(em & ((1ull << lane) - 1))] = t.unit;
+        }
     }
 
     // ---- results of the units this wave owns --------------------------------------------------------------

@@ -545,7 +545,14 @@ def test_properties_at_scale(oracle, dcn, genome, index_pair):
     keep, hits, total = proc.filter_batch(bases, offsets)
     # idempotence
     keep2, hits2, total2 = proc.filter_batch(bases, offsets)
-    assert (keep == keep2).all() and (hits == hits2).all() and (total == total2).all()
+    if not ((keep == keep2).all() and (hits == hits2).all() and (total == total2).all()):
+        full = oracle.filter_batch(oidx, bases, offsets, threads=8)
+        msg = []
+        for name, got in (("call1", (keep, hits, total)), ("call2", (keep2, hits2, total2))):
+            for j, what in enumerate(("keep", "hits", "total")):
+                d = np.nonzero(got[j] != full[j])[0]
+                msg.append(f"{name}.{what}: {len(d)} differ from the oracle" + (f", units {d[0]}..{d[-1]}, got {got[j][d[:4]]} want {full[j][d[:4]]}" if len(d) else ""))
+        raise AssertionError("two calls on the same batch disagree: " + "; ".join(msg))
     # strand symmetry: the reverse complement of every read has the same minimizer multiset
     comp = np.zeros(256, np.uint8)
     comp[list(b"ACGT")] = list(b"TGCA")

@@ -371,7 +371,7 @@ struct dcn_ctx {
     // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
     // units whose hits do not fit the LDS set of the distinct pass (4 slots per record of capacity)
     uint64_t *d_rec_hash = nullptr;
-    uint32_t *d_tile_hits = nullptr, *d_pending = nullptr;
+    uint32_t *d_tile_hits = nullptr, *d_pending = nullptr, *d_big = nullptr;
     uint64_t rec_capacity = 0;
     uint64_t *d_set_slots = nullptr;
     dcn_status *d_status = nullptr;
@@ -455,7 +455,7 @@ void free_ctx(dcn_ctx *c) {
     void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask,
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
                    c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
-                   c->d_set_off, c->d_tile_hits, c->d_pending, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
+                   c->d_set_off, c->d_tile_hits, c->d_pending, c->d_big, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
     for (void *p : dev)
         if (p) hipFree(p);
@@ -637,6 +637,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     da.n_units = n_units;
     da.status = c->d_status;
     da.caps = c->d_caps;
+    da.big = c->d_big;
     DCN_TRY(dcn_launch_distinct(da, st));
     DCN_PROF_MARK(DCN_STAGE_DISTINCT);
 
@@ -1001,6 +1002,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_set_off, MR + 1, "set_off");
     A(d_tile_hits, mt, "tile_hits");
     A(d_pending, MR, "pending");
+    A(d_big, MR, "big");
     A(d_rec_hash, max_batch_bases + 64, "rec_hash");
     A(d_status, 1, "status");
     A(d_report, 1, "report");
@@ -1736,6 +1738,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         da.n_units = n_units;
         da.status = c->d_status;
         da.caps = c->d_caps;
+        da.big = c->d_big;
         DCN_TRY(dcn_launch_distinct(da, st));
         dcn_finish_args fa;
         fa.n_units = n_units;

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
                 while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
                 a.set_off[u] = (uint32_t)atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
                 a.caps[u] = cap;
-                a.status->any_big = 1;
+                a.big[atomicAdd(&a.status->n_big, 1u)] = u;
+                if (count == 0xFFFFFFFFu) a.status->any_scattered = 1;
             }
             continue;
         }
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
 }
 
 __global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, dcn_status *status) {
-    if (status->any_big == 0) return;
+    if (status->n_big == 0) return;
     uint64_t total = status->set_cursor;
     if (total > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) status->rec_overflow = 1;
@@ -257,42 +258,80 @@ __global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) set_slots[i] = 0;
 }
 
-// Pass B, one wave per tile of a unit with a global set: CAS-insert the tile's run, one atomicAdd of the number of
-// new keys per tile.
+// CAS-insert the run of `n` hashes at rec_hash[slot0 ..] into `region`; returns the number of new keys (wave-wide)
+__device__ inline uint32_t insert_run(const uint64_t *rec_hash, uint64_t slot0, uint32_t n, unsigned long long *region,
+                                      uint32_t cap, uint32_t lane) {
+    uint32_t fresh_n = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        bool fresh = false;
+        if (j < n) {
+            const uint64_t h = rec_hash[slot0 + j];
+            if (h != 0) {
+                uint32_t sl = set_slot_of(h, cap);
+                for (;;) {
+                    unsigned long long old = atomicCAS(&region[sl], 0ull, (unsigned long long)h);
+                    if (old == 0) {
+                        fresh = true;
+                        break;
+                    }
+                    if (old == h) break;
+                    sl = (sl + 1) & (cap - 1);
+                }
+            }
+        }
+        fresh_n += (uint32_t)__popcll(__ballot(fresh));
+    }
+    return fresh_n;
+}
+
+// Pass B, one workgroup per unit with a global set: its waves share the unit's tiles (64 per step), find the runs
+// hanging on them and CAS-insert those; one atomicAdd of the number of new keys per wave.
 __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
-    if (a.status->any_big == 0 || a.status->set_cursor > a.set_capacity) return;
+    const uint32_t NB = a.status->n_big;
+    if (NB == 0 || a.status->set_cursor > a.set_capacity) return;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t bi = blockIdx.x; bi < NB; bi += gridDim.x) {
+        const uint32_t u = a.big[bi];
+        const uint32_t first = a.unit_tile_first[u], count = a.unit_tile_count[u];
+        if (count == 0xFFFFFFFFu) continue; // scattered_insert_kernel
+        const uint32_t cap = a.caps[u];
+        unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
+        uint32_t fresh_n = 0;
+        for (uint32_t t0 = wave * 64; t0 < count; t0 += 256) {
+            const uint32_t t = t0 + lane;
+            const uint32_t n = t < count ? a.tile_hits[first + t] : 0u;
+            uint64_t slot0 = 0;
+            if (n) {
+                const dcn_tile tl = a.tiles[first + t];
+                slot0 = tl.scan_start + (tl.flags & 1u);
+            }
+            unsigned long long runs = __ballot(n != 0);
+            while (runs) {
+                const int r = __ffsll((long long)runs) - 1;
+                runs &= runs - 1;
+                fresh_n += insert_run(a.rec_hash, (uint64_t)__shfl((long long)slot0, r, 64), __shfl(n, r, 64), region, cap, lane);
+            }
+        }
+        if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[u], fresh_n);
+    }
+}
+
+// The same for units whose tiles are not contiguous in the tile array (a unit of three or more reads cut by a planning
+// block; never a single read or a pair): nothing lists their tiles, so every tile of the batch is looked at.
+__global__ __launch_bounds__(256) void scattered_insert_kernel(dcn_distinct_args a) {
+    if (a.status->any_scattered == 0 || a.status->set_cursor > a.set_capacity) return;
     const uint32_t NT = *a.n_tiles;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t t = wave; t < NT; t += n_waves) {
         const dcn_tile tl = a.tiles[t];
-        if (a.unit_state[tl.unit]) continue;
+        if (a.unit_state[tl.unit] || a.unit_tile_count[tl.unit] != 0xFFFFFFFFu) continue;
         const uint32_t cap = a.caps[tl.unit];
-        if (!cap) continue;
         const uint32_t n = a.tile_hits[t];
-        unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[tl.unit]);
-        const uint64_t slot0 = tl.scan_start + (tl.flags & 1u);
-        uint32_t fresh_n = 0;
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-            const uint32_t j = j0 + lane;
-            bool fresh = false;
-            if (j < n) {
-                const uint64_t h = a.rec_hash[slot0 + j];
-                if (h != 0) {
-                    uint32_t sl = set_slot_of(h, cap);
-                    for (;;) {
-                        unsigned long long old = atomicCAS(&region[sl], 0ull, (unsigned long long)h);
-                        if (old == 0) {
-                            fresh = true;
-                            break;
-                        }
-                        if (old == h) break;
-                        sl = (sl + 1) & (cap - 1);
-                    }
-                }
-            }
-            fresh_n += (uint32_t)__popcll(__ballot(fresh));
-        }
+        if (!cap || !n) continue;
+        const uint32_t fresh_n = insert_run(a.rec_hash, tl.scan_start + (tl.flags & 1u), n,
+                                            (unsigned long long *)(a.set_slots + a.set_off[tl.unit]), cap, lane);
         if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[tl.unit], fresh_n);
     }
 }
@@ -425,6 +464,7 @@ int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream) {
     hipLaunchKernelGGL(unit_distinct_kernel, dim3(std::max(1u, std::min(a.n_units, 256u * 10u))), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_capacity, a.status);
     hipLaunchKernelGGL(big_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(scattered_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }

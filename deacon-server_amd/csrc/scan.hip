@@ -49,6 +49,14 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+#ifndef DCN_LIST_BY_LANE
+#define DCN_LIST_BY_LANE 1 // 0: the round-1 layout list[entry][lane], kept for A/B timing
+#endif
+#if DCN_LIST_BY_LANE
+#define DCN_LIST_AT(lane_, entry_) list[lane_][entry_]
+#else
+#define DCN_LIST_AT(lane_, entry_) list[entry_][lane_]
+#endif
 constexpr int DCN_LSTRIDE = 42;  // u16 entries per list row: DCN_LCAP + 2, 21 dwords
 static_assert(DCN_LSTRIDE >= DCN_LCAP && (DCN_LSTRIDE / 2) % 2 == 1 && DCN_LSTRIDE % 2 == 0, "odd dword stride");
 constexpr int DCN_RCAP = 256; // LDS ring of the most recent hits; a unit resolved in-wave has <= RCAP-64 items
@@ -59,7 +67,11 @@ struct WaveShared {
     // number of dwords: phase A's store of entry cnt by every lane, and phase B's read of consecutive entries of one
     // lane by consecutive lanes, both spread over the banks (rows of 64 lanes x u16 put a lane's whole list on one
     // bank: phase B then read it 13-way conflicted on average)
+#if DCN_LIST_BY_LANE
     uint16_t list[DCN_WAVE][DCN_LSTRIDE];
+#else
+    uint16_t list[DCN_LCAP + 2][DCN_WAVE];
+#endif
     uint64_t ring_hash[DCN_RCAP];
     uint32_t total[DCN_WAVE];           // per unit slot: emitted minimizers minus those failing the ACGT test
     uint32_t hits[DCN_WAVE];            // per unit slot: distinct hits
@@ -71,7 +83,6 @@ struct WaveShared {
     uint8_t head_of[DCN_WAVE];          // unit slot -> its first lane in this wave
     uint8_t local[DCN_WAVE];            // unit slot has all its tiles in this wave
     uint8_t lok[DCN_WAVE];              // unit slot is being resolved inside this wave
-    uint8_t ncont[DCN_WAVE];            // unit slot's tiles are not contiguous (a unit cut by a planning block)
 };
 
 #ifndef DCN_EXP
@@ -135,19 +146,15 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     sh.hraw[lane] = 0;
     sh.lok[lane] = 0;
     sh.uhits[lane] = 0;
-    bool unit_starts_here = false; // this lane holds the first tile of its unit (the wave that enrols the unit below)
     if (head) {
         sh.unit_of[uslot] = t.unit;
         sh.head_of[uslot] = (uint8_t)lane;
-        bool loc = false, nc = false;
+        bool loc = false;
         if (!DUMP) {
             uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
-            nc = count == 0xFFFFFFFFu;
-            loc = !nc && first >= wave_first && first + count <= wave_first + DCN_WAVE;
-            unit_starts_here = have_tile && first == tile_idx;
+            loc = count != 0xFFFFFFFFu && first >= wave_first && first + count <= wave_first + DCN_WAVE;
         }
         sh.local[uslot] = loc ? 1 : 0;
-        sh.ncont[uslot] = nc ? 1 : 0;
     }
     if (lane < 16) {
         uint32_t in = lane & 3, out = lane >> 2;
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 uint32_t e = E + u * DCN_WAVE + lane;
                 idx[u] = act[u] ? e - sh.start[lo[u]] : 0;
                 uint32_t o_skip = __shfl(skip0, lo[u], 64);
-                rel[u] = sh.list[lo[u]][idx[u] + o_skip];
+                rel[u] = sh.DCN_LIST_AT(lo[u], idx[u] + o_skip);
                 long long o_s = __shfl((long long)s, lo[u], 64);
                 o_uslot[u] = __shfl(uslot, lo[u], 64);
                 p[u] = (uint64_t)(o_s + rel[u]);
@@ -339,9 +346,9 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 // are in flat order, so a unit's hits occupy consecutive ring slots: a hit with `run` earlier hits
                 // of its unit (earlier rounds: sh.hraw, this round: ballot arithmetic) compares with the `run`
                 // slots before it.
-                {
+                const unsigned long long hb = __ballot(lok);
+                if (hb) { // wave-uniform
                     const unsigned long long lt = (1ull << lane) - 1;
-                    const unsigned long long hb = __ballot(lok);
                     const uint32_t nh = (uint32_t)__popcll(hb);
                     const uint32_t rank = (uint32_t)__popcll(hb & lt);
                     const uint32_t x = n_ring + rank;
@@ -350,7 +357,8 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
                     const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
                     const bool run_head = lok && (below == 0 || prev_us != o_uslot[u]);
-                    const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
+                    const unsigned long long hm_all = __ballot(run_head);
+                    const unsigned long long hm = hm_all & (lt | (1ull << lane));
                     const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
                     const uint32_t rank_head = (uint32_t)__popcll(hb & ((1ull << head_lane) - 1));
                     const uint32_t run = lok ? sh.hraw[o_uslot[u]] + (rank - rank_head) : 0u;
@@ -364,9 +372,15 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         dup |= (d0 + 0 < run && v0 == hash[u]) | (d0 + 1 < run && v1 == hash[u]) |
                                (d0 + 2 < run && v2 == hash[u]) | (d0 + 3 < run && v3 == hash[u]);
                     }
-                    if (lok) {
-                        atomicAdd(&sh.hraw[o_uslot[u]], 1u);
-                        if (!dup) atomicAdd(&sh.hits[o_uslot[u]], 1u);
+                    // a unit's hits of this round are one run of adjacent hit lanes: its first lane books the whole run
+                    // (one LDS update per run instead of a same-address atomic per hit lane)
+                    const unsigned long long db = __ballot(dup);
+                    if (run_head) {
+                        const unsigned long long later = hm_all & ~((2ull << lane) - 1);
+                        const unsigned long long upto = later ? ((1ull << (__ffsll((long long)later) - 1)) - 1) : ~0ull;
+                        const unsigned long long rm = hb & upto & ~lt;
+                        sh.hraw[o_uslot[u]] += (uint32_t)__popcll(rm);
+                        sh.hits[o_uslot[u]] += (uint32_t)__popcll(rm & ~db);
                     }
                     n_ring += nh;
                     __syncthreads();
@@ -387,7 +401,8 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
                         const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
                         const bool run_head = rec && (below == 0 || prev_us != o_uslot[u]);
-                        const unsigned long long hm = __ballot(run_head) & (lt | (1ull << lane));
+                        const unsigned long long hm_all = __ballot(run_head);
+                        const unsigned long long hm = hm_all & (lt | (1ull << lane));
                         const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
                         const uint32_t rank = (uint32_t)__popcll(below) - (uint32_t)__popcll(rb & ((1ull << head_lane) - 1));
                         const uint32_t unit_lane = sh.head_of[o_uslot[u]];
@@ -399,7 +414,11 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                             a.rec_hash[(uint64_t)o_s + o_carry + before + rank] = hash[u];
                             if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
-                        if (rec) atomicAdd(&sh.uhits[o_uslot[u]], 1u); // after every lane of the run has read the old length
+                        if (run_head) { // after every lane of the run has read the old length: one update per run
+                            const unsigned long long later = hm_all & ~((2ull << lane) - 1);
+                            const unsigned long long upto = later ? ((1ull << (__ffsll((long long)later) - 1)) - 1) : ~0ull;
+                            sh.uhits[o_uslot[u]] += (uint32_t)__popcll(rb & upto & ~lt);
+                        }
                     }
                 }
             }
@@ -551,7 +570,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     // FIRST: window 0, always emitted (a carry tile's copy is dropped in phase B);
                     // later blocks: window j-(w-1) >= 1, emitted when in range and different from its predecessor
                     const bool emit = FIRST ? (nwc > 0) : ((j - (w - 1) < nwc) && sel != prev);
-                    if (!(DCN_EXP & 4)) sh.list[lane][cnt] = (uint16_t)sel;
+                    if (!(DCN_EXP & 4)) sh.DCN_LIST_AT(lane, cnt) = (uint16_t)sel;
                     cnt += emit ? 1u : 0u;
                     prev = sel;
                 }
@@ -560,7 +579,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 const uint32_t i = j - (w - 1); // window index; wraps while j < w-1
                 const bool in_range = i < nwc;  // unsigned compare: false while i is "negative"
                 const bool emit = in_range && sel != prev;
-                sh.list[lane][cnt] = (uint16_t)sel;
+                sh.DCN_LIST_AT(lane, cnt) = (uint16_t)sel;
                 cnt += emit ? 1u : 0u;
                 prev = in_range ? sel : prev;
             }
@@ -659,7 +678,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 const bool actv = j < cnt_eff && nh < need;
                 if (!__any(actv)) break;
                 uint64_t hash;
-                const uint32_t rel = sh.list[lane][(actv ? j : 0u) + skip0];
+                const uint32_t rel = sh.DCN_LIST_AT(lane, (actv ? j : 0u) + skip0);
                 const bool hit = probe_item((uint64_t)(s + rel), actv, hash);
                 // both lanes of a pair apply the unit's hits in the same order (first mate's, then second mate's)
                 const bool p_hit = __shfl((int)hit, partner, 64) != 0;
@@ -693,7 +712,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     const uint32_t o_skip = __shfl(skip0, lo, 64);
                     const uint32_t o_nh = __shfl(nh, lo, 64);
                     const long long o_s = __shfl((long long)s, lo, 64);
-                    const uint32_t rel = sh.list[lo][idx + o_skip];
+                    const uint32_t rel = sh.DCN_LIST_AT(lo, idx + o_skip);
                     uint64_t hash;
                     const bool hit = probe_item((uint64_t)(o_s + rel), act && o_nh < need, hash);
                     // hand each hit to its owner lane, one at a time (rare for reads that are not from the index)
@@ -725,13 +744,14 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     if (any_rec && lane == 0) a.status->any_records = 1;
     {
         const bool pending = have_tile && !sh.lok[uslot];
+        bool enrol = false;
         if (pending) {
             const uint32_t th = head ? sh.uhits[uslot] : 0u; // the run hangs on the unit's first tile in this wave
             a.tile_hits[tile_idx] = th;
-            if (th) atomicAdd(&a.g_hitcnt[t.unit], th); // one per (wave, unit)
+            // one atomic per (wave, unit) with hits; whoever finds the unit's count at zero puts it on the work list
+            // (a unit without any hit needs no distinct pass: its count stays 0)
+            if (th) enrol = atomicAdd(&a.g_hitcnt[t.unit], th) == 0u;
         }
-        // the wave holding a unit's first tile puts it on the distinct pass's work list
-        const bool enrol = pending && unit_starts_here;
         const unsigned long long em = __ballot(enrol);
         if (em) {
             uint32_t base = 0;

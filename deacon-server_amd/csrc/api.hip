@@ -305,6 +305,7 @@ extern "C" void dcn_index_destroy(dcn_index *index) {
 struct dcn_chunk {
     uint32_t r0 = 0, r1 = 0, u0 = 0, u1 = 0;
     uint64_t b0 = 0, b1 = 0;
+    uint64_t max_len = 0; // longest read of the chunk
 };
 
 // One host batch in flight (dcn_filter_batch_submit .. dcn_filter_batch_wait).  Everything a later batch's copies
@@ -327,6 +328,7 @@ struct dcn_slot {
     uint32_t *h_hits = nullptr, *h_total = nullptr;
     dcn_batch_report *h_report = nullptr;
     hipEvent_t done = nullptr;
+    std::vector<hipEvent_t> ev_h2d, ev_comp; // one pair per chunk, grown on demand
     // the submitted batch, kept for result delivery and for the re-run after a record overflow
     dcn_params params = {};
     bool device_pack = false; // ASCII crossed the link: the pack kernel runs, read ends are probed for a newline
@@ -442,6 +444,8 @@ void free_slot_buffers(dcn_slot &sl) {
     for (void *p : host)
         if (p) hipHostFree(p);
     if (sl.done) hipEventDestroy(sl.done);
+    for (hipEvent_t e : sl.ev_h2d) hipEventDestroy(e);
+    for (hipEvent_t e : sl.ev_comp) hipEventDestroy(e);
     sl = dcn_slot();
 }
 
@@ -594,7 +598,8 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     // decisions only: largest list length whose required hits still equal abs_threshold (dcn_required_hits is
     // monotone in the total); the scan kernel's lanes then stop at abs_threshold distinct hits (scan.hip)
     sa.early_out_max_items = 0;
-    if (!v.d_hits && !v.d_total && params->abs_threshold >= 1 && params->abs_threshold <= 4 && !getenv("DCN_NO_EARLY_OUT")) {
+    static const bool no_early_out = getenv("DCN_NO_EARLY_OUT") != nullptr, no_early_out_pairs = getenv("DCN_NO_EARLY_OUT_PAIRS") != nullptr;
+    if (!v.d_hits && !v.d_total && params->abs_threshold >= 1 && params->abs_threshold <= 4 && !no_early_out) {
         uint32_t lo = 0, hi = 65535; // required(lo) == abs always holds for lo = 0
         while (lo < hi) {
             uint32_t mid = (lo + hi + 1) / 2;
@@ -602,7 +607,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
             else hi = mid - 1;
         }
         sa.early_out_max_items = lo;
-        sa.early_out_pairs = getenv("DCN_NO_EARLY_OUT_PAIRS") ? 0u : 1u;
+        sa.early_out_pairs = no_early_out_pairs ? 0u : 1u;
     }
     sa.keep = v.d_keep;
     sa.hits = v.d_hits;
@@ -958,7 +963,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
         return dcn_fail(DCN_ERR_ARG, "batch limits imply more than 2^32 tiles");
     }
     c->max_tiles = (uint32_t)mt;
-    c->chunk_bases = 32ull << 20;
+    c->chunk_bases = 64ull << 20;
     if (const char *cb = getenv("DCN_CHUNK_BASES")) {
         long long v = atoll(cb);
         if (v >= 1024) c->chunk_bases = (uint64_t)v;
@@ -1157,13 +1162,16 @@ int ensure_pinned(T **p, uint64_t count) {
 
 // Validates reads [r0, ...) of the batch and returns the end of the chunk that starts at r0: the first unit
 // boundary at which the chunk holds at least chunk_bases bases (or the end of the batch).
-int next_chunk(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t n_bases_total, uint32_t *r1_out) {
+int next_chunk(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t n_bases_total, uint32_t *r1_out,
+               uint64_t *max_len_out) {
     const uint64_t *off = in.offsets;
     const uint32_t *uid = in.unit_id;
     const uint64_t b0 = off[r0], target = b0 + c->chunk_bases;
     uint32_t r = r0;
+    uint64_t max_len = 0;
     for (;;) {
         if (off[r + 1] < off[r]) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
+        max_len = std::max(max_len, off[r + 1] - off[r]);
         if (off[r + 1] - off[r] > 0xFFFFFFF0ull) return dcn_fail(DCN_ERR_ARG, "read longer than 2^32 bases");
         if (off[r + 1] > n_bases_total) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
         ++r;
@@ -1176,17 +1184,25 @@ int next_chunk(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t n_ba
         if (off[r] >= target) break;
     }
     *r1_out = r;
+    *max_len_out = max_len;
+    return DCN_OK;
+}
+
+int chunk_events(dcn_slot &sl, size_t n) {
+    while (sl.ev_h2d.size() < n) {
+        hipEvent_t a = nullptr, b = nullptr;
+        DCN_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        sl.ev_h2d.push_back(a);
+        DCN_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        sl.ev_comp.push_back(b);
+    }
     return DCN_OK;
 }
 
 // kernels + result copies of one chunk (its inputs are on the device, or on their way on the copy stream)
-int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, const dcn_chunk &ch, bool wait_h2d) {
-    const int e = c->ev_next;
-    c->ev_next = (e + 1) % dcn_ctx::N_EV;
-    if (wait_h2d) {
-        DCN_HIP(hipEventRecord(c->ev_h2d[e], c->copy_stream));
-        DCN_HIP(hipStreamWaitEvent(c->stream, c->ev_h2d[e], 0));
-    }
+int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d) {
+    const dcn_chunk &ch = sl.chunks[ci];
+    if (wait_h2d) DCN_HIP(hipStreamWaitEvent(c->stream, sl.ev_h2d[ci], 0));
     BatchView v;
     v.d_ascii = sl.device_pack ? sl.d_ascii : nullptr;
     v.d_packed = sl.d_packed;
@@ -1204,8 +1220,8 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, const dcn_chunk &ch, bool wait_h2d) 
     v.d_total = sl.counts ? sl.d_total + ch.u0 : nullptr;
     v.d_report = sl.d_report;
     DCN_TRY(enqueue_batch(c, v, &sl.params));
-    DCN_HIP(hipEventRecord(c->ev_comp[e], c->stream));
-    DCN_HIP(hipStreamWaitEvent(c->d2h_stream, c->ev_comp[e], 0));
+    DCN_HIP(hipEventRecord(sl.ev_comp[ci], c->stream));
+    DCN_HIP(hipStreamWaitEvent(c->d2h_stream, sl.ev_comp[ci], 0));
     const uint32_t nu = ch.u1 - ch.u0;
     DCN_HIP(hipMemcpyAsync((sl.keep_direct ? sl.u_keep : sl.h_keep) + ch.u0, sl.d_keep + ch.u0, nu, hipMemcpyDeviceToHost,
                            c->d2h_stream));
@@ -1289,13 +1305,16 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         DCN_HIP(hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream));
         bool saw_newline = false;
         int rc = DCN_OK;
+        if (n_reads && off_pinned) rc = staged_h2d(c, sl.d_offsets, in.offsets, (uint64_t)(n_reads + 1) * sizeof(uint64_t), 1);
+        if (rc == DCN_OK && n_reads && in.unit_id && uid_pinned)
+            rc = staged_h2d(c, sl.d_unit_id, in.unit_id, (uint64_t)n_reads * sizeof(uint32_t), 1);
         uint32_t r0 = 0, u0 = 0;
         uint64_t groups_done = 0; // 32-base groups of the stream already sent (HostPacked / Packed)
         while (r0 < n_reads && rc == DCN_OK) {
             dcn_chunk ch;
             ch.r0 = r0;
             ch.u0 = u0;
-            if ((rc = next_chunk(c, in, r0, n_bases, &ch.r1)) != DCN_OK) break;
+            if ((rc = next_chunk(c, in, r0, n_bases, &ch.r1, &ch.max_len)) != DCN_OK) break;
             ch.u1 = in.unit_id ? (ch.r1 == n_reads ? in.unit_id[n_reads - 1] + 1 : in.unit_id[ch.r1]) : ch.r1;
             ch.b0 = in.offsets[ch.r0];
             ch.b1 = in.offsets[ch.r1];
@@ -1344,18 +1363,30 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                         }
                     }
                 }
-                DCN_TRY(staged_h2d(c, sl.d_offsets + ch.r0, in.offsets + ch.r0, (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t), off_pinned));
-                if (in.unit_id)
-                    DCN_TRY(staged_h2d(c, sl.d_unit_id + ch.r0, in.unit_id + ch.r0, (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t), uid_pinned));
+                // page-locked offsets / unit ids went over in one copy each before the first chunk (two runtime calls
+                // less per chunk); pageable ones are staged chunk by chunk
+                if (!off_pinned)
+                    DCN_TRY(staged_h2d(c, sl.d_offsets + ch.r0, in.offsets + ch.r0, (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t), 0));
+                if (in.unit_id && !uid_pinned)
+                    DCN_TRY(staged_h2d(c, sl.d_unit_id + ch.r0, in.unit_id + ch.r0, (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t), 0));
                 return DCN_OK;
             };
             if ((rc = copies()) != DCN_OK) break;
             if (saw_newline) break; // this attempt is abandoned
-            if ((rc = enqueue_chunk(c, sl, ch, true)) != DCN_OK) break;
             sl.chunks.push_back(ch);
+            if ((rc = chunk_events(sl, sl.chunks.size())) != DCN_OK) break;
+            hipError_t he = hipEventRecord(sl.ev_h2d[sl.chunks.size() - 1], c->copy_stream);
+            if (he != hipSuccess) {
+                rc = dcn_fail(DCN_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(he));
+                break;
+            }
             r0 = ch.r1;
             u0 = ch.u1;
         }
+        // second pass: the kernels.  Every copy is already queued, so the link never waits for the host to get round
+        // to the next chunk (a chunk's ~15 runtime calls cost about as much host time as its copy takes on the link)
+        for (size_t ci = 0; rc == DCN_OK && !saw_newline && ci < sl.chunks.size(); ++ci) rc = enqueue_chunk(c, sl, ci, true);
+
         n_units = u0;
         if (rc == DCN_OK && saw_newline && attempt == 0) {
             drain(c);
@@ -1407,8 +1438,8 @@ int wait_impl(dcn_ctx *c, uint64_t ticket) {
         if (rc != DCN_OK) return fail(rc);
         if (hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream) != hipSuccess)
             return fail(dcn_fail(DCN_ERR_HIP, "hipMemsetAsync failed"));
-        for (const dcn_chunk &ch : sl.chunks)
-            if ((rc = enqueue_chunk(c, sl, ch, false)) != DCN_OK) return fail(rc);
+        for (size_t ci = 0; ci < sl.chunks.size(); ++ci)
+            if ((rc = enqueue_chunk(c, sl, ci, false)) != DCN_OK) return fail(rc);
         if ((rc = finish_submission(c, sl)) != DCN_OK) return fail(rc);
     }
     if (!sl.keep_direct && sl.n_units) memcpy(sl.u_keep, sl.h_keep, sl.n_units);

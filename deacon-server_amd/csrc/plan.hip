@@ -188,14 +188,25 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
             continue;
         }
         if (count == 0xFFFFFFFFu || H > DCN_LDS_SET_MAX) {
-            // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor
+            // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor.  Pass B clears the
+            // region of a unit it owns as a workgroup; a scattered unit's region is filled by waves all over the
+            // grid, so it is cleared here
+            uint32_t cap = 64;
+            while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
+            unsigned long long off = 0;
+            if (lane == 0) off = atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
+            off = (unsigned long long)__shfl((long long)off, 0, 64);
+            const bool fits = off + cap <= a.set_capacity;
             if (lane == 0) {
-                uint32_t cap = 64;
-                while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
-                a.set_off[u] = (uint32_t)atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
-                a.caps[u] = cap;
-                a.big[atomicAdd(&a.status->n_big, 1u)] = u;
-                if (count == 0xFFFFFFFFu) a.status->any_scattered = 1;
+                a.set_off[u] = (uint32_t)off;
+                a.caps[u] = fits ? cap : 0u;
+                if (!fits) a.status->rec_overflow = 1;
+                else a.big[atomicAdd(&a.status->n_big, 1u)] = u;
+                if (fits && count == 0xFFFFFFFFu) a.status->any_scattered = 1;
+            }
+            if (fits && count == 0xFFFFFFFFu) {
+                for (uint32_t q = lane; q < cap; q += 64) a.set_slots[off + q] = 0;
+                __threadfence();
             }
             continue;
         }
@@ -207,9 +218,10 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
         uint32_t distinct = 0;
         for (uint32_t t0 = 0; t0 < count; t0 += 64) {
             const uint32_t t = t0 + lane;
-            const uint32_t n = t < count ? a.tile_hits[first + t] : 0u;
+            uint32_t n = 0;
             uint64_t slot0 = 0;
-            if (n) {
+            if (t < count) { // both loads issued together
+                n = a.tile_hits[first + t];
                 const dcn_tile tl = a.tiles[first + t];
                 slot0 = tl.scan_start + (tl.flags & 1u);
             }
@@ -219,23 +231,30 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
                 runs &= runs - 1;
                 const uint32_t rn = __shfl(n, r, 64);
                 const uint64_t rs = (uint64_t)__shfl((long long)slot0, r, 64);
-                for (uint32_t j0 = 0; j0 < rn; j0 += 64) {
-                    const uint32_t j = j0 + lane;
-                    const uint64_t h = j < rn ? a.rec_hash[rs + j] : 0ull;
-                    bool fresh = false;
-                    if (h != 0) {
-                        uint32_t sl = set_slot_of(h, cap);
-                        for (;;) {
-                            unsigned long long old = atomicCAS(&set[sl], 0ull, (unsigned long long)h);
-                            if (old == 0) {
-                                fresh = true;
-                                break;
-                            }
-                            if (old == h) break;
-                            sl = (sl + 1) & (cap - 1);
-                        }
+                for (uint32_t j0 = 0; j0 < rn; j0 += 256) { // four loads in flight per lane
+                    uint64_t h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t j = j0 + q * 64 + lane;
+                        h[q] = j < rn ? a.rec_hash[rs + j] : 0ull;
                     }
-                    distinct += (uint32_t)__popcll(__ballot(fresh));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        bool fresh = false;
+                        if (h[q] != 0) {
+                            uint32_t sl = set_slot_of(h[q], cap);
+                            for (;;) {
+                                unsigned long long old = atomicCAS(&set[sl], 0ull, (unsigned long long)h[q]);
+                                if (old == 0) {
+                                    fresh = true;
+                                    break;
+                                }
+                                if (old == h[q]) break;
+                                sl = (sl + 1) & (cap - 1);
+                            }
+                        }
+                        distinct += (uint32_t)__popcll(__ballot(fresh));
+                    }
                 }
             }
         }
@@ -247,62 +266,69 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
     }
 }
 
-__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, dcn_status *status) {
-    if (status->n_big == 0) return;
-    uint64_t total = status->set_cursor;
-    if (total > capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) status->rec_overflow = 1;
-        return;
-    }
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) set_slots[i] = 0;
-}
-
 // CAS-insert the run of `n` hashes at rec_hash[slot0 ..] into `region`; returns the number of new keys (wave-wide)
 __device__ inline uint32_t insert_run(const uint64_t *rec_hash, uint64_t slot0, uint32_t n, unsigned long long *region,
                                       uint32_t cap, uint32_t lane) {
     uint32_t fresh_n = 0;
-    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        bool fresh = false;
-        if (j < n) {
-            const uint64_t h = rec_hash[slot0 + j];
-            if (h != 0) {
-                uint32_t sl = set_slot_of(h, cap);
+    for (uint32_t j0 = 0; j0 < n; j0 += 256) { // four keys per lane: their loads, then their first CAS, in flight together
+        uint64_t h[4];
+        uint32_t sl[4];
+        unsigned long long old[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = j0 + q * 64 + lane;
+            h[q] = j < n ? rec_hash[slot0 + j] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sl[q] = set_slot_of(h[q], cap);
+            old[q] = h[q] ? atomicCAS(&region[sl[q]], 0ull, (unsigned long long)h[q]) : h[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bool fresh = false;
+            if (h[q] != 0) {
+                unsigned long long o = old[q];
                 for (;;) {
-                    unsigned long long old = atomicCAS(&region[sl], 0ull, (unsigned long long)h);
-                    if (old == 0) {
+                    if (o == 0) {
                         fresh = true;
                         break;
                     }
-                    if (old == h) break;
-                    sl = (sl + 1) & (cap - 1);
+                    if (o == h[q]) break;
+                    sl[q] = (sl[q] + 1) & (cap - 1);
+                    o = atomicCAS(&region[sl[q]], 0ull, (unsigned long long)h[q]);
                 }
             }
+            fresh_n += (uint32_t)__popcll(__ballot(fresh));
         }
-        fresh_n += (uint32_t)__popcll(__ballot(fresh));
     }
     return fresh_n;
 }
 
-// Pass B, one workgroup per unit with a global set: its waves share the unit's tiles (64 per step), find the runs
-// hanging on them and CAS-insert those; one atomicAdd of the number of new keys per wave.
+// Pass B, one workgroup per unit with a global set: clear the unit's region, then its waves share the unit's tiles
+// (64 per step), find the runs hanging on them and CAS-insert those; one atomicAdd of the number of new keys per
+// wave.  Units whose tiles are not contiguous in the tile array (a unit of three or more reads cut by a planning
+// block; never a single read or a pair) have no tile list: if there is one, every tile of the batch is looked at.
 __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
     const uint32_t NB = a.status->n_big;
-    if (NB == 0 || a.status->set_cursor > a.set_capacity) return;
+    if (NB == 0 || a.status->rec_overflow) return;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t bi = blockIdx.x; bi < NB; bi += gridDim.x) {
         const uint32_t u = a.big[bi];
         const uint32_t first = a.unit_tile_first[u], count = a.unit_tile_count[u];
-        if (count == 0xFFFFFFFFu) continue; // scattered_insert_kernel
+        if (count == 0xFFFFFFFFu) continue; // below
         const uint32_t cap = a.caps[u];
         unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
+        for (uint32_t q = threadIdx.x; q < cap; q += blockDim.x) region[q] = 0;
+        __threadfence();
+        __syncthreads();
         uint32_t fresh_n = 0;
         for (uint32_t t0 = wave * 64; t0 < count; t0 += 256) {
             const uint32_t t = t0 + lane;
-            const uint32_t n = t < count ? a.tile_hits[first + t] : 0u;
+            uint32_t n = 0;
             uint64_t slot0 = 0;
-            if (n) {
+            if (t < count) {
+                n = a.tile_hits[first + t];
                 const dcn_tile tl = a.tiles[first + t];
                 slot0 = tl.scan_start + (tl.flags & 1u);
             }
@@ -315,16 +341,10 @@ __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
         }
         if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[u], fresh_n);
     }
-}
-
-// The same for units whose tiles are not contiguous in the tile array (a unit of three or more reads cut by a planning
-// block; never a single read or a pair): nothing lists their tiles, so every tile of the batch is looked at.
-__global__ __launch_bounds__(256) void scattered_insert_kernel(dcn_distinct_args a) {
-    if (a.status->any_scattered == 0 || a.status->set_cursor > a.set_capacity) return;
+    if (a.status->any_scattered == 0) return;
     const uint32_t NT = *a.n_tiles;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t t = wave; t < NT; t += n_waves) {
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t t = gwave; t < NT; t += n_waves) {
         const dcn_tile tl = a.tiles[t];
         if (a.unit_state[tl.unit] || a.unit_tile_count[tl.unit] != 0xFFFFFFFFu) continue;
         const uint32_t cap = a.caps[tl.unit];
@@ -462,9 +482,7 @@ int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream) {
 
 int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream) {
     hipLaunchKernelGGL(unit_distinct_kernel, dim3(std::max(1u, std::min(a.n_units, 256u * 10u))), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(distinct_clear_kernel, dim3(2048), dim3(256), 0, stream, a.set_slots, a.set_capacity, a.status);
     hipLaunchKernelGGL(big_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(scattered_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;
 }

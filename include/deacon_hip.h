@@ -151,7 +151,7 @@ void dcn_ctx_destroy(dcn_ctx *ctx);
  * keep and the six counters are identical in both forms.
  *
  * Blocking (= dcn_filter_batch_submit + dcn_filter_batch_wait).  Inside, the batch is cut at unit boundaries into
- * chunks of ~32 Mbp: chunk i's kernels run while chunk i+1 crosses PCIe on a side stream and chunk i-1's results
+ * chunks of ~64 Mbp (DCN_CHUNK_BASES): chunk i's kernels run while chunk i+1 crosses PCIe on a side stream and chunk i-1's results
  * travel back on a third.  What crosses the link depends on where `bases` lives:
  *   page-locked memory (dcn_host_alloc / hipHostRegister)  the ASCII is DMA'd as it is and packed on the device;
  *   pageable memory   host threads pack it to 2 bits + 1 mask bit per base straight into the context's pinned

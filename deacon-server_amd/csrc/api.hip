@@ -535,6 +535,7 @@ struct BatchView {
     uint32_t unit_base = 0;
     uint32_t n_reads = 0, n_units = 0;
     uint64_t b0 = 0, b1 = 0; // bases of the stream this view covers
+    uint64_t stream_bases = 0; // bases of the whole stream
     uint8_t *d_keep = nullptr;
     uint32_t *d_hits = nullptr, *d_total = nullptr;
     dcn_batch_report *d_report = nullptr;
@@ -592,6 +593,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     sa.table = idx->view();
     sa.k = idx->k;
     sa.w = idx->w;
+    sa.stream_bases = v.stream_bases;
     sa.abs_threshold = params->abs_threshold;
     sa.rel_threshold = params->rel_threshold;
     sa.deplete = params->deplete;
@@ -684,6 +686,10 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     if (!c->batch_pending) return DCN_OK;
     c->batch_pending = false;
     DCN_HIP(hipMemcpy(c->h_report, c->d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost));
+    if (c->h_report->bounds) {
+        DCN_HIP(hipMemsetAsync(c->d_report, 0, offsetof(dcn_batch_report, stats), c->stream));
+        return dcn_fail(DCN_ERR_INTERNAL, "scan kernel: index out of range in phase B (DCN_DEBUG_BOUNDS build)");
+    }
     if (c->h_report->overflow) {
         const uint64_t need = c->h_report->need;
         DCN_HIP(hipMemsetAsync(c->d_report, 0, offsetof(dcn_batch_report, stats), c->stream)); // re-arm, ordered before the next batch
@@ -1081,6 +1087,7 @@ extern "C" int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, con
     v.n_units = n_units;
     v.b0 = 0;
     v.b1 = n_bases;
+    v.stream_bases = n_bases;
     v.d_keep = d_keep;
     v.d_hits = d_hits;
     v.d_total = d_total;
@@ -1215,6 +1222,7 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d) {
     // ASCII chunks are copied and packed in whole 32-base groups (see submit_impl)
     v.b0 = ch.b0 / 32 * 32;
     v.b1 = std::min<uint64_t>((ch.b1 + 31) / 32 * 32, sl.n_bases);
+    v.stream_bases = sl.n_bases;
     v.d_keep = sl.d_keep + ch.u0;
     v.d_hits = sl.counts ? sl.d_hits + ch.u0 : nullptr;
     v.d_total = sl.counts ? sl.d_total + ch.u0 : nullptr;
@@ -1427,6 +1435,7 @@ int wait_impl(dcn_ctx *c, uint64_t ticket) {
     for (int attempt = 0;; ++attempt) {
         hipError_t e = hipEventSynchronize(sl.done);
         if (e != hipSuccess) return fail(dcn_fail(DCN_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e)));
+        if (sl.h_report->bounds) return fail(dcn_fail(DCN_ERR_INTERNAL, "scan kernel: index out of range in phase B (DCN_DEBUG_BOUNDS build)"));
         if (!sl.h_report->overflow) break;
         // Some chunk dropped hit records.  Grow the scratch and run the batch's kernels again: its inputs are still
         // resident in the slot.  Everything else in flight is drained first, since the scratch is shared.
@@ -1649,6 +1658,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     sa.table = c->index->view();
     sa.k = c->index->k;
     sa.w = c->index->w;
+    sa.stream_bases = n_bases;
     sa.status = c->d_status;
     sa.dump_hash = c->d_dump_hash;
     sa.dump_pos = c->d_dump_pos;
@@ -1876,6 +1886,7 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             sa.table = idx->view();
             sa.k = idx->k;
             sa.w = idx->w;
+            sa.stream_bases = nb;
             sa.status = c->d_status;
             sa.dump_hash = c->d_dump_hash;
             sa.dump_pos = c->d_dump_pos;

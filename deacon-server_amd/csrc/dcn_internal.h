@@ -98,6 +98,7 @@ struct dcn_status {
     uint32_t any_scattered;        // ... one of them with tiles that are not contiguous (found by a sweep over all tiles)
     uint32_t n_pending;            // units enrolled for the distinct pass (scan.hip)
     uint32_t any_newline;          // the pack kernel saw a '\n' byte: only then does planning probe read ends
+    uint32_t bounds;               // DCN_DEBUG_BOUNDS builds: phase B met an index outside its list / its stream
     unsigned long long set_cursor; // distinct pass: slots handed out to the global per-unit hash sets
 };
 
@@ -106,7 +107,7 @@ struct dcn_status {
 struct dcn_batch_report {
     uint32_t overflow;                     // a chunk dropped hit records: its multi-wave units were decided from
                                            // truncated records and its counters were skipped
-    uint32_t reserved;
+    uint32_t bounds;                       // DCN_DEBUG_BOUNDS builds only: the scan kernel refused an out-of-range index
     unsigned long long need;               // record capacity (set slots / 4) that would have sufficed
     unsigned long long stats[DCN_N_STATS]; // the six ProcessingStats counters
 };
@@ -120,6 +121,7 @@ struct dcn_scan_args {
     const uint32_t *unit_tile_count; // n_units: number of tiles, 0xFFFFFFFF when they are not contiguous
     dcn_table_view table;
     uint32_t k, w;
+    uint64_t stream_bases; // bases of the packed stream (checked by DCN_DEBUG_BOUNDS builds only)
     // thresholds
     uint64_t abs_threshold;
     double rel_threshold;

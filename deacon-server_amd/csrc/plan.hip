@@ -387,6 +387,7 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
             }
         }
     }
+    if (a.status->bounds && blockIdx.x == 0 && threadIdx.x == 0) a.report->bounds = a.status->bounds;
     if (a.status->rec_overflow) {
         // sticky: the status words are cleared before the next chunk, the report is read when the batch is waited for
         if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -253,10 +253,27 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 uint32_t e = E + u * DCN_WAVE + lane;
                 idx[u] = act[u] ? e - sh.start[lo[u]] : 0;
                 uint32_t o_skip = __shfl(skip0, lo[u], 64);
+#ifdef DCN_DEBUG_BOUNDS
+                // the owner search puts idx inside the owner's list (idx < its entry count <= DCN_LCAP); a build that
+                // broke the search (round 1's timing-only "no owner" experiment) read list rows far outside, took the
+                // garbage as a position and faulted on the packed stream past its tail pad
+                if (act[u] && (lo[u] > 63u || idx[u] + o_skip >= (uint32_t)DCN_LCAP + 2u)) {
+                    a.status->bounds = 1;
+                    act[u] = false;
+                    idx[u] = 0;
+                }
+#endif
                 rel[u] = sh.DCN_LIST_AT(lo[u], idx[u] + o_skip);
                 long long o_s = __shfl((long long)s, lo[u], 64);
                 o_uslot[u] = __shfl(uslot, lo[u], 64);
                 p[u] = (uint64_t)(o_s + rel[u]);
+#ifdef DCN_DEBUG_BOUNDS
+                if (act[u] && p[u] + k > a.stream_bases) { // a minimizer's k-mer lies inside its read, hence inside the stream
+                    a.status->bounds = 2;
+                    act[u] = false;
+                    p[u] = 0;
+                }
+#endif
             }
             uint32_t mw[U][3], pw[U][NPW];
 #pragma unroll

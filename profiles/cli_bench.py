@@ -43,7 +43,7 @@ try:
             print(os.path.basename(BIN), " ".join(envs), end=": ", flush=True)
         t = time.perf_counter()
         subprocess.run([BIN, "filter", os.path.join(d, "g.idx"), fq, "-o", os.path.join(d, f"out_{run_no}.fq"), "-s",
-                        os.path.join(d, "s.json"), "-q", *extra], check=True, env=env)
+                        os.path.join(d, "s.json"), "-q", *extra, *os.environ.get("DCN_CLI_ARGS", "").split()], check=True, env=env)
         dt = time.perf_counter() - t
         s = json.load(open(os.path.join(d, "s.json")))
         os.unlink(os.path.join(d, f"out_{run_no}.fq"))

@@ -434,8 +434,30 @@ def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
     b, o = oracle.concat_reads(reads)
     keep, _, _ = oracle.filter_batch(oidx, b, o)
     want = [f"r{i} +x @y" for i in range(len(reads)) if keep[i]]
-    for name, payload in (("unix.fq", data), ("nofinalnl.fq", data[:-1]), ("dos.fq", data.replace(b"\n", b"\r\n"))):
+    repeated_id = b"".join(l.replace(b"\n+\n", b"\n+" + l[1:l.index(b"\n")] + b"\n", 1) if i % 7 == 0 else l for i, l in enumerate(lines))
+    for name, payload in (("unix.fq", data), ("nofinalnl.fq", data[:-1]), ("dos.fq", data.replace(b"\n", b"\r\n")),
+                          ("plusid.fq", repeated_id)):
         (tmp_path / name).write_bytes(payload)
         out = run("filter", idx, tmp_path / name, "-t", 6).stdout
         got = [l[1:].rstrip(b"\r").decode() for l in out.split(b"\n")[0::4] if l]
         assert got == want, name
+        # -o to a plain file goes through the shared output mapping (record bytes copied as they are where they
+        # already have the output form, formatted field by field otherwise): byte-identical to the stream writer
+        for extra in ([], ["-R"]):
+            run("filter", idx, tmp_path / name, "-t", 6, "-o", tmp_path / "mapped.fq", *extra)
+            monkeypatch.setenv("DCN_CLI_NO_MMAP_OUT", "1")
+            run("filter", idx, tmp_path / name, "-t", 6, "-o", tmp_path / "streamed.fq", *extra)
+            monkeypatch.delenv("DCN_CLI_NO_MMAP_OUT")
+            assert (tmp_path / "mapped.fq").read_bytes() == (tmp_path / "streamed.fq").read_bytes(), (name, extra)
+            if not extra:
+                assert (tmp_path / "mapped.fq").read_bytes() == out, name
+    # FASTA in (single- and multi-line records mixed) through the mapping
+    fa = b"".join((b">s%d d\n%s\n" % (i, r)) if i % 2 else (b">s%d d\n%s\n%s\n" % (i, r[:30], r[30:])) for i, r in enumerate(reads[:5000]))
+    (tmp_path / "in.fa").write_bytes(fa)
+    out = run("filter", idx, tmp_path / "in.fa").stdout
+    run("filter", idx, tmp_path / "in.fa", "-o", tmp_path / "mapped.fa")
+    assert (tmp_path / "mapped.fa").read_bytes() == out
+    assert [l[1:].decode() for l in out.split(b"\n")[0::2] if l] == [f"s{i} d" for i in range(5000) if keep[i]]
+    # nothing kept: an empty file, not the reservation
+    run("filter", idx, tmp_path / "in.fa", "-a", 60000, "-o", tmp_path / "none.fa")
+    assert (tmp_path / "none.fa").stat().st_size == 0

@@ -431,7 +431,12 @@ void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &ou
         r.id_len = (uint32_t)(trim(p + 1, e0) - (p + 1));
         r.seq_off = out.bases.size();
         if (fastq) {
-            size_t s1 = e0 + 1, e1 = line_end(d, b, s1), s2 = e1 + 1, e2 = line_end(d, b, s2), s3 = e2 + 1, e3 = line_end(d, b, s3);
+            // two of the four line ends are where the first two put them in a well-formed record ("+\n", then a
+            // quality line as long as the sequence line): look there before searching
+            size_t s1 = e0 + 1, e1 = line_end(d, b, s1), s2 = e1 + 1;
+            size_t e2 = (s2 + 1 < b && d[s2 + 1] == '\n') ? s2 + 1 : line_end(d, b, s2);
+            size_t s3 = e2 + 1, e3 = s3 + (e1 - s1);
+            if (e3 > b || (e3 < b && d[e3] != '\n') || std::memchr(d + s3, '\n', e3 - s3)) e3 = line_end(d, b, s3);
             if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
             size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
             out.bases.insert(out.bases.end(), d + s1, d + t1);
@@ -546,6 +551,14 @@ BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base
     const size_t per_unit = b.paired ? 2 : 1;
     uint64_t counter = rename_base;
     char *o = dst;
+    // the mapping's pages do not exist yet: one madvise for the batch instead of a fault per page
+    static const bool populate = !std::getenv("DCN_CLI_NO_POPULATE");
+#ifdef MADV_POPULATE_WRITE
+    if (populate && expect) {
+        const uintptr_t pa = (uintptr_t)dst & ~(uintptr_t)4095, pb = ((uintptr_t)dst + expect + 4095) & ~(uintptr_t)4095;
+        (void)madvise((void *)pa, pb - pa, MADV_POPULATE_WRITE);  // best effort (older kernels: EINVAL, pages fault in as before)
+    }
+#endif
     uint64_t run_off = 0, run_len = 0;  // pending verbatim run in the input mapping
     auto flush_run = [&] {
         if (run_len) std::memcpy(o, chars + run_off, run_len), o += run_len, run_len = 0;

@@ -351,7 +351,7 @@ struct dcn_ctx {
     int ev_next = 0, stage_next = 0;
     uint64_t max_bases = 0;
     uint32_t max_reads = 0;
-    uint32_t tile_windows = 512;
+    uint32_t tile_windows = 256; // long reads: 12 % faster scan than 512 (fewer mid-scan flushes per wave), 128 and 1024 slower (profiles/r02_tile_sweep.txt)
     uint32_t max_tiles = 0;
     uint64_t chunk_bases = 0; // pipeline granularity of the host API (DCN_CHUNK_BASES)
     // device inputs (host API staging targets of slot 0; also used by the minimizer dump and the index build)

@@ -89,7 +89,8 @@ struct WaveShared {
 #define DCN_EXP 0 // experiment bits (timing-only builds, results wrong): 1 = no set probe, 2 = no phase B,
                   // 4 = no list store, 8 = no duplicate compare, 16 = no mask loads,
                   // 64 = k / l streams reuse the in-stream words (2 instead of 6 stream loads per block),
-                  // 128 = no stream loads at all in the main loop (words recycled)
+                  // 128 = no stream loads at all in the main loop (words recycled), 256 = hits of units the wave does not
+                  // finish are not written to their runs
 #endif
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 // A zero hash (0 marks an empty set slot there) is flagged per unit instead of counted there.
                 {
                     const bool rec = hit[u] && !lok;
-                    const unsigned long long rb = __ballot(rec);
+                    const unsigned long long rb = (DCN_EXP & 256) ? 0ull : __ballot(rec);
                     if (rb) { // wave-uniform
                         const unsigned long long lt = (1ull << lane) - 1;
                         const unsigned long long below = rb & lt;

@@ -80,7 +80,7 @@ struct WaveShared {
     uint32_t unit_of[DCN_WAVE];         // unit slot -> global unit id
     uint16_t start[DCN_WAVE + 2];       // exclusive prefix of the per-lane list lengths
     uint32_t uhits[DCN_WAVE];           // per unit slot: hits written to the unit's run of the record array so far
-    uint8_t head_of[DCN_WAVE];          // unit slot -> its first lane in this wave
+    uint64_t run_base[DCN_WAVE];        // per unit slot: first slot of the unit's run (scan_start + carry of its first tile here)
     uint8_t local[DCN_WAVE];            // unit slot has all its tiles in this wave
     uint8_t lok[DCN_WAVE];              // unit slot is being resolved inside this wave
 };
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     sh.uhits[lane] = 0;
     if (head) {
         sh.unit_of[uslot] = t.unit;
-        sh.head_of[uslot] = (uint8_t)lane;
+        sh.run_base[uslot] = t.scan_start + (t.flags & 1u);
         bool loc = false;
         if (!DUMP) {
             uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
@@ -423,13 +423,10 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         const unsigned long long hm = hm_all & (lt | (1ull << lane));
                         const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
                         const uint32_t rank = (uint32_t)__popcll(below) - (uint32_t)__popcll(rb & ((1ull << head_lane) - 1));
-                        const uint32_t unit_lane = sh.head_of[o_uslot[u]];
-                        const long long o_s = __shfl((long long)s, unit_lane, 64);
-                        const uint32_t o_carry = __shfl(carry, unit_lane, 64);
                         any_rec = true;
                         if (rec) {
                             const uint32_t before = sh.uhits[o_uslot[u]];
-                            a.rec_hash[(uint64_t)o_s + o_carry + before + rank] = hash[u];
+                            a.rec_hash[sh.run_base[o_uslot[u]] + before + rank] = hash[u];
                             if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
                         if (run_head) { // after every lane of the run has read the old length: one update per run

@@ -15,7 +15,7 @@
 // before the GPU is initialised) -> GPU stage (its own thread and context) -> format kept records on a pool
 // (format_record_to_buffer, src/local_filter.rs:60-92) -> one writer thread.  Output keeps the input order (the reference's depends on worker scheduling).
 // The server/client commands live in deacon-server_amd/server.py / client.py.
-// Input/output compression: gzip via zlib; zstd and xz are not available in this build.
+// Input/output compression: gzip via zlib; zstd and xz through the installed runtime libraries (codecs.hpp).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -39,6 +40,7 @@
 #include <thread>
 #include <vector>
 
+#include "codecs.hpp"
 #include "deacon_hip.hpp"
 
 namespace {
@@ -60,60 +62,180 @@ bool ends_with(const std::string &s, const char *suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
-// ---- input: plain or gzip, file or stdin (niffler's role in src/local_filter.rs:41-55) -------------------------
+// ---- input: plain, gzip, zstd or xz by content, file or stdin (niffler's role in src/local_filter.rs:41-55) ---------
 class Input {
   public:
-    explicit Input(const std::string &path) {
-        if (path == "-") gz_ = gzdopen(0, "rb");
-        else gz_ = gzopen(path.c_str(), "rb");  // zlib reads plain files transparently
-        if (!gz_) die("Failed to open file " + path);
-        gzbuffer(gz_, 1 << 20);
+    explicit Input(const std::string &path) : raw_(1 << 20) {
+        fd_ = path == "-" ? 0 : ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) die("Failed to open file " + path);
+        refill();
+        const unsigned char *m = (const unsigned char *)raw_.data();
+        const size_t n = end_;
+        std::string why;
+        if (codecs::is_gzip_magic(m, n)) {
+            kind_ = GZIP;
+            std::memset(&zs_, 0, sizeof zs_);
+            if (inflateInit2(&zs_, 15 + 32) != Z_OK) die("zlib initialisation failed");
+        } else if (codecs::is_zstd_magic(m, n)) {
+            kind_ = ZSTD;
+            zstd_ = codecs::Zstd::get(&why);
+            if (!zstd_) die("zstd input " + path + ": " + why);
+            zds_ = zstd_->createDStream();
+            if (!zds_ || zstd_->isError(zstd_->initDStream(zds_))) die("zstd initialisation failed");
+        } else if (codecs::is_xz_magic(m, n)) {
+            kind_ = XZ;
+            lzma_ = codecs::Lzma::get(&why);
+            if (!lzma_) die("xz input " + path + ": " + why);
+            std::memset(&ls_, 0, sizeof ls_);
+            if (lzma_->stream_decoder(&ls_, UINT64_MAX, codecs::LZMA_CONCATENATED) != codecs::LZMA_OK) die("xz initialisation failed");
+        }
     }
     ~Input() {
-        if (gz_) gzclose(gz_);
+        if (kind_ == GZIP) inflateEnd(&zs_);
+        if (kind_ == ZSTD && zds_) zstd_->freeDStream(zds_);
+        if (kind_ == XZ) lzma_->end(&ls_);
+        if (fd_ > 0) ::close(fd_);
     }
     size_t read(char *dst, size_t n) {
         size_t got = 0;
-        while (got < n) {
-            int r = gzread(gz_, dst + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
-            if (r < 0) die("read error");
-            if (r == 0) break;
-            got += (size_t)r;
+        while (got < n && !done_) {
+            if (pos_ == end_ && !raw_eof_) refill();
+            const size_t avail = end_ - pos_;
+            if (kind_ == PLAIN) {
+                if (!avail) break;
+                const size_t m = std::min(avail, n - got);
+                std::memcpy(dst + got, raw_.data() + pos_, m);
+                pos_ += m;
+                got += m;
+            } else if (kind_ == GZIP) {
+                if (!avail && raw_eof_) {
+                    if (mid_stream_) die("read error: truncated gzip stream");
+                    break;
+                }
+                zs_.next_in = (Bytef *)(raw_.data() + pos_);
+                zs_.avail_in = (uInt)avail;
+                zs_.next_out = (Bytef *)(dst + got);
+                zs_.avail_out = (uInt)std::min<size_t>(n - got, 1u << 30);
+                const uInt out0 = zs_.avail_out;
+                int r = inflate(&zs_, Z_NO_FLUSH);
+                if (r != Z_OK && r != Z_STREAM_END && r != Z_BUF_ERROR) die("read error: invalid gzip stream");
+                pos_ += avail - zs_.avail_in;
+                got += out0 - zs_.avail_out;
+                mid_stream_ = r != Z_STREAM_END;
+                if (r == Z_STREAM_END && inflateReset(&zs_) != Z_OK) die("zlib reset failed");  // next member (bgzip, cat a.gz b.gz)
+            } else if (kind_ == ZSTD) {
+                if (!avail && raw_eof_) {
+                    if (mid_stream_) die("read error: truncated zstd stream");
+                    break;
+                }
+                codecs::ZSTD_inBuffer in = {raw_.data() + pos_, avail, 0};
+                codecs::ZSTD_outBuffer out = {dst + got, n - got, 0};
+                const size_t r = zstd_->decompressStream(zds_, &out, &in);
+                if (zstd_->isError(r)) die(std::string("read error: zstd: ") + zstd_->getErrorName(r));
+                pos_ += in.pos;
+                got += out.pos;
+                mid_stream_ = r != 0;  // 0: a frame just ended
+            } else {
+                ls_.next_in = (const uint8_t *)(raw_.data() + pos_);
+                ls_.avail_in = avail;
+                ls_.next_out = (uint8_t *)(dst + got);
+                ls_.avail_out = n - got;
+                const int r = lzma_->code(&ls_, raw_eof_ && !avail ? codecs::LZMA_FINISH : codecs::LZMA_RUN);
+                pos_ += avail - ls_.avail_in;
+                got += (n - got) - ls_.avail_out;
+                if (r == codecs::LZMA_STREAM_END) done_ = true;
+                else if (r != codecs::LZMA_OK) die("read error: invalid xz stream");
+            }
         }
         return got;
     }
 
   private:
-    gzFile gz_ = nullptr;
+    void refill() {
+        pos_ = end_ = 0;
+        while (end_ < raw_.size() && !raw_eof_) {
+            ssize_t r = ::read(fd_, raw_.data() + end_, raw_.size() - end_);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                die("read error");
+            }
+            if (r == 0) raw_eof_ = true;
+            else end_ += (size_t)r;
+            if (end_ >= 4096) break;  // enough to go on with; pipes deliver what they have
+        }
+    }
+    enum Kind { PLAIN, GZIP, ZSTD, XZ } kind_ = PLAIN;
+    int fd_ = -1;
+    std::vector<char> raw_;
+    size_t pos_ = 0, end_ = 0;
+    bool raw_eof_ = false, done_ = false, mid_stream_ = false;
+    z_stream zs_;
+    const codecs::Zstd *zstd_ = nullptr;
+    void *zds_ = nullptr;
+    const codecs::Lzma *lzma_ = nullptr;
+    codecs::lzma_stream ls_;
 };
 
-// ---- output: plain or gzip (get_writer, src/local_filter.rs:110-151) ------------------------------------------
+// ---- output: plain, gzip, zstd or xz by extension (get_writer, src/local_filter.rs:110-151) ---------------------------
 class Output {
   public:
     Output(const std::string &path, int level) {
-        if (ends_with(path, ".zst") || ends_with(path, ".xz")) die("zstd / xz output is not available in this build: " + path);
+        std::string why;
         if (ends_with(path, ".gz")) {
             if (level < 1 || level > 9) die("Invalid gzip compression level " + std::to_string(level) + ". Must be between 1 and 9.");
             std::string mode = "wb" + std::to_string(level);
             gz_ = gzopen(path.c_str(), mode.c_str());
             if (!gz_) die("Failed to create output file: " + path);
             gzbuffer(gz_, 1 << 20);
-        } else if (path == "-") {
+            return;
+        }
+        if (ends_with(path, ".zst")) {
+            if (level < 1 || level > 22) die("Invalid zstd compression level " + std::to_string(level) + ". Must be between 1 and 22.");
+            zstd_ = codecs::Zstd::get(&why);
+            if (!zstd_) die("zstd output " + path + ": " + why);
+            zcs_ = zstd_->createCStream();
+            if (!zcs_ || zstd_->isError(zstd_->initCStream(zcs_, level))) die("zstd initialisation failed");
+        } else if (ends_with(path, ".xz")) {
+            if (level < 0 || level > 9) die("Invalid xz compression level " + std::to_string(level) + ". Must be between 0 and 9.");
+            lzma_ = codecs::Lzma::get(&why);
+            if (!lzma_) die("xz output " + path + ": " + why);
+            std::memset(&ls_, 0, sizeof ls_);
+            if (lzma_->easy_encoder(&ls_, (uint32_t)level, codecs::LZMA_CHECK_CRC64) != codecs::LZMA_OK) die("xz initialisation failed");
+            xz_ = true;
+        }
+        if (path == "-") {
             f_ = stdout;
         } else {
             f_ = std::fopen(path.c_str(), "wb");
             if (!f_) die("Failed to create output file: " + path);
             own_ = true;
         }
-        if (f_) std::setvbuf(f_, nullptr, _IONBF, 0);  // batches arrive as multi-megabyte buffers: no second copy
+        std::setvbuf(f_, nullptr, _IONBF, 0);  // batches arrive as multi-megabyte buffers: no second copy
+        if (zcs_ || xz_) cbuf_.resize(1 << 20);
     }
     ~Output() { close(); }
     void write(const std::vector<char> &buf) {
         if (buf.empty()) return;
         if (gz_) {
             if (gzwrite(gz_, buf.data(), (unsigned)buf.size()) != (int)buf.size()) die("write error");
-        } else if (std::fwrite(buf.data(), 1, buf.size(), f_) != buf.size()) {
-            die("write error");
+        } else if (zcs_) {
+            codecs::ZSTD_inBuffer in = {buf.data(), buf.size(), 0};
+            while (in.pos < in.size) {
+                codecs::ZSTD_outBuffer out = {cbuf_.data(), cbuf_.size(), 0};
+                if (zstd_->isError(zstd_->compressStream(zcs_, &out, &in))) die("write error: zstd");
+                raw_write(cbuf_.data(), out.pos);
+            }
+        } else if (xz_) {
+            ls_.next_in = (const uint8_t *)buf.data();
+            ls_.avail_in = buf.size();
+            while (ls_.avail_in) {
+                ls_.next_out = (uint8_t *)cbuf_.data();
+                ls_.avail_out = cbuf_.size();
+                if (lzma_->code(&ls_, codecs::LZMA_RUN) != codecs::LZMA_OK) die("write error: xz");
+                raw_write(cbuf_.data(), cbuf_.size() - ls_.avail_out);
+            }
+        } else {
+            raw_write(buf.data(), buf.size());
         }
     }
     // the last flush is where a full disk or a closed pipe shows: a failure here must not end in "Retained ..."
@@ -123,6 +245,30 @@ class Output {
         gz_ = nullptr;
         f_ = nullptr;
         if (gz && gzclose(gz) != Z_OK) die("write error");
+        if (f && zcs_) {
+            size_t left = 1;
+            while (left) {
+                codecs::ZSTD_outBuffer out = {cbuf_.data(), cbuf_.size(), 0};
+                left = zstd_->endStream(zcs_, &out);
+                if (zstd_->isError(left)) die("write error: zstd");
+                f_ = f, raw_write(cbuf_.data(), out.pos), f_ = nullptr;
+            }
+            zstd_->freeCStream(zcs_);
+            zcs_ = nullptr;
+        }
+        if (f && xz_) {
+            int r = codecs::LZMA_OK;
+            ls_.avail_in = 0;
+            while (r == codecs::LZMA_OK) {
+                ls_.next_out = (uint8_t *)cbuf_.data();
+                ls_.avail_out = cbuf_.size();
+                r = lzma_->code(&ls_, codecs::LZMA_FINISH);
+                if (r != codecs::LZMA_OK && r != codecs::LZMA_STREAM_END) die("write error: xz");
+                f_ = f, raw_write(cbuf_.data(), cbuf_.size() - ls_.avail_out), f_ = nullptr;
+            }
+            lzma_->end(&ls_);
+            xz_ = false;
+        }
         if (f) {
             if (std::fflush(f) != 0) die("write error");
             if (own_ && std::fclose(f) != 0) die("write error");
@@ -130,9 +276,17 @@ class Output {
     }
 
   private:
+    void raw_write(const char *p, size_t n) {
+        if (n && std::fwrite(p, 1, n, f_) != n) die("write error");
+    }
     gzFile gz_ = nullptr;
     FILE *f_ = nullptr;
-    bool own_ = false;
+    bool own_ = false, xz_ = false;
+    const codecs::Zstd *zstd_ = nullptr;
+    void *zcs_ = nullptr;
+    const codecs::Lzma *lzma_ = nullptr;
+    codecs::lzma_stream ls_;
+    std::vector<char> cbuf_;
 };
 
 // ---- FASTA / FASTQ records -------------------------------------------------------------------------------------
@@ -373,7 +527,8 @@ struct MappedFile {
         if (p == MAP_FAILED) return false;
         data = (const char *)p;
         size = (size_t)st.st_size;
-        if ((unsigned char)data[0] == 0x1f && (unsigned char)data[1] == 0x8b) {  // gzip: use the streaming reader
+        const unsigned char *m = (const unsigned char *)data;
+        if (codecs::is_gzip_magic(m, size) || codecs::is_zstd_magic(m, size) || codecs::is_xz_magic(m, size)) {  // compressed: the streaming reader
             munmap(p, size);
             data = nullptr;
             return false;

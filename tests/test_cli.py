@@ -89,19 +89,69 @@ def test_filter_to_file_and_summary(tmp_path):  # filter_tests.rs:92-128
                       "bp_per_second"}  # FilterSummary, src/filter_common.rs:11-38
 
 
+def _zstd():
+    import ctypes
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_compressBound.restype = ctypes.c_size_t
+    z.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+    z.ZSTD_compress.restype = ctypes.c_size_t
+    z.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+    z.ZSTD_decompress.restype = ctypes.c_size_t
+    z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    z.ZSTD_isError.restype = ctypes.c_uint
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    return z
+
+
+def zstd_compress(data, level=3):
+    import ctypes
+    z = _zstd()
+    buf = ctypes.create_string_buffer(z.ZSTD_compressBound(len(data)))
+    n = z.ZSTD_compress(buf, len(buf), data, len(data), level)
+    assert not z.ZSTD_isError(n)
+    return buf.raw[:n]
+
+
+def zstd_decompress(data, max_out=1 << 26):
+    import ctypes
+    z = _zstd()
+    buf = ctypes.create_string_buffer(max_out)
+    n = z.ZSTD_decompress(buf, max_out, data, len(data))
+    assert not z.ZSTD_isError(n)
+    return buf.raw[:n]
+
+
 @gpu
-def test_filter_gzip_output_and_unsupported_codecs(tmp_path):  # filter_tests.rs:131-215
+def test_filter_compressed_outputs_and_inputs(tmp_path):  # filter_tests.rs:131-215 (gzip, zstd, xz by extension)
+    import lzma
     idx = build_index(tmp_path, [("seq1", SEQ1), ("seq2", SEQ2)])
     fastq(tmp_path / "reads.fastq", [("seq1", SEQ1), ("seq2", SEQ2)])
-    out = tmp_path / "filtered.fastq.gz"
-    run("filter", idx, tmp_path / "reads.fastq", "-o", out)
-    assert gzip.open(out).read().count(b"@seq") == 2
-    for ext in ("zst", "xz"):  # documented difference: only gzip is available in this build
-        p = run("filter", idx, tmp_path / "reads.fastq", "-o", tmp_path / f"f.fastq.{ext}", check=False)
-        assert p.returncode != 0 and b"not available" in p.stderr
-    gz_in = tmp_path / "reads.fastq.gz"
-    gz_in.write_bytes(gzip.compress((tmp_path / "reads.fastq").read_bytes()))
-    assert run("filter", idx, gz_in).stdout.count(b"@seq") == 2  # compressed input is detected
+    plain = run("filter", idx, tmp_path / "reads.fastq").stdout
+    assert plain.count(b"@seq") == 2
+    decoders = {"gz": gzip.decompress, "zst": zstd_decompress, "xz": lzma.decompress}
+    for ext, dec in decoders.items():  # written by this build, read by an independent decoder
+        out = tmp_path / f"filtered.fastq.{ext}"
+        run("filter", idx, tmp_path / "reads.fastq", "-o", out)
+        assert out.stat().st_size > 0 and dec(out.read_bytes()) == plain, ext
+        assert run("filter", idx, out).stdout == plain, ext  # and read back by this build (format found by content)
+    for ext, lo, hi in (("gz", 1, 9), ("zst", 1, 22), ("xz", 0, 9)):  # validate_compression_level, local_filter.rs:95-107
+        p = run("filter", idx, tmp_path / "reads.fastq", "-o", tmp_path / f"x.{ext}", "--compression-level", hi + 1, check=False)
+        assert p.returncode != 0 and b"compression level" in p.stderr, ext
+        run("filter", idx, tmp_path / "reads.fastq", "-o", tmp_path / f"x.{ext}", "--compression-level", hi)
+    # compressed inputs written by independent encoders, several members / frames / streams in one file, and stdin
+    raw = (tmp_path / "reads.fastq").read_bytes()
+    half = raw.index(b"@seq2")
+    members = {"gz": gzip.compress(raw[:half]) + gzip.compress(raw[half:]),
+               "zst": zstd_compress(raw[:half]) + zstd_compress(raw[half:]),
+               "xz": lzma.compress(raw[:half]) + lzma.compress(raw[half:])}
+    for ext, blob in members.items():
+        f = tmp_path / f"in.fastq.{ext}"
+        f.write_bytes(blob)
+        assert run("filter", idx, f).stdout == plain, ext
+        assert run("filter", idx, "-", stdin=blob).stdout == plain, ext
+    assert run("filter", idx, "-", stdin=raw).stdout == plain
+    p = run("filter", idx, "-", stdin=members["zst"][:-7], check=False)
+    assert p.returncode != 0 and b"zstd" in p.stderr
 
 
 @gpu

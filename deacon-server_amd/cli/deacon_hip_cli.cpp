@@ -19,6 +19,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -238,6 +239,30 @@ class Output {
             raw_write(buf.data(), buf.size());
         }
     }
+    bool plain() const { return !gz_ && !zcs_ && !xz_; }
+    // plain streams only: the pieces of a batch in one gather write per IOV_MAX entries
+    void write_gather(std::vector<struct iovec> &iov) {
+        const int fd = fileno(f_);
+        size_t i = 0;
+        while (i < iov.size()) {
+            const int n = (int)std::min<size_t>(iov.size() - i, 1024);
+            ssize_t w = ::writev(fd, iov.data() + i, n);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                die("write error");
+            }
+            while (w > 0 && i < iov.size()) {  // a short write ends inside some entry
+                if ((size_t)w >= iov[i].iov_len) {
+                    w -= (ssize_t)iov[i].iov_len;
+                    ++i;
+                } else {
+                    iov[i].iov_base = (char *)iov[i].iov_base + w;
+                    iov[i].iov_len -= (size_t)w;
+                    w = 0;
+                }
+            }
+        }
+    }
     // the last flush is where a full disk or a closed pipe shows: a failure here must not end in "Retained ..."
     void close() {
         gzFile gz = gz_;
@@ -309,6 +334,8 @@ struct Batch {
     const char *ext = nullptr;   // ... or the memory-mapped input file they live in (parallel reader)
     const char *chars() const { return ext ? ext : text.data(); }
     std::vector<char> out1, out2;  // formatted kept records (filled by the format stage)
+    std::vector<struct iovec> iov1;  // plain single-file output: what to write, in order -- ranges of the mapped input
+                                     // (records that already have their output form) and pieces of out1
     std::vector<uint8_t> bases;  // concatenated sequences (what dcn_filter_batch takes)
     std::vector<uint64_t> offsets{0};
     std::vector<uint32_t> unit_id;
@@ -755,6 +782,74 @@ BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base
     return st;
 }
 
+// Gather form for a plain output stream: nothing is copied for records whose input bytes already are their output
+// (adjacent ones coalesce into one range of the mapped input); the rest is formatted into b.out1 and referenced from
+// there.  The writer hands the list to writev(2): one copy, made by the kernel.
+BatchStats format_batch_gather(Batch &b, bool rename, uint64_t rename_base) {
+    BatchStats st;
+    const char *chars = b.chars();
+    const size_t per_unit = b.paired ? 2 : 1;
+    uint64_t counter = rename_base;
+    b.iov1.clear();
+    b.out1.clear();
+    // formatted pieces are appended to out1; their iovecs hold OFFSETS until out1 stops growing
+    std::vector<std::pair<size_t, size_t>> fixups;  // (iovec index, offset in out1)
+    bool last_formatted = false;                    // the last iovec is a formatted piece (extendable in out1)
+    uint64_t need = 0;
+    for (size_t i = 0; i < b.recs.size(); ++i)
+        if (b.keep[i / per_unit] && !(b.recs[i].rec_len && !rename)) need += 2 * (uint64_t)b.recs[i].seq_len + b.recs[i].id_len + 32;
+    b.out1.reserve(need);
+    for (size_t i = 0; i < b.recs.size(); ++i) {
+        const Rec &r = b.recs[i];
+        st.total_seqs++;
+        st.total_bp += r.seq_len;
+        if (!b.keep[i / per_unit]) {
+            st.filtered_seqs++;
+            st.filtered_bp += r.seq_len;
+            continue;
+        }
+        st.output_bp += r.seq_len;
+        st.kept_records++;
+        counter++;
+        if (r.rec_len && !rename) {
+            const char *p = chars + r.rec_off;
+            if (!b.iov1.empty() && !last_formatted && (const char *)b.iov1.back().iov_base + b.iov1.back().iov_len == p)
+                b.iov1.back().iov_len += r.rec_len;
+            else b.iov1.push_back({(void *)p, r.rec_len});
+            last_formatted = false;
+            continue;
+        }
+        const size_t at = b.out1.size();
+        const bool fasta = r.qual_off == NO_QUAL;
+        b.out1.push_back(fasta ? '>' : '@');
+        if (rename) {
+            char num[24];
+            int n = std::snprintf(num, sizeof num, "%llu", (unsigned long long)counter);
+            b.out1.insert(b.out1.end(), num, num + n);
+        } else {
+            b.out1.insert(b.out1.end(), chars + r.id_off, chars + r.id_off + r.id_len);
+        }
+        b.out1.push_back('\n');
+        b.out1.insert(b.out1.end(), b.bases.begin() + r.seq_off, b.bases.begin() + r.seq_off + r.seq_len);
+        if (fasta) {
+            b.out1.push_back('\n');
+        } else {
+            b.out1.insert(b.out1.end(), {'\n', '+', '\n'});
+            b.out1.insert(b.out1.end(), chars + r.qual_off, chars + r.qual_off + r.seq_len);
+            b.out1.push_back('\n');
+        }
+        if (last_formatted) {
+            b.iov1.back().iov_len += b.out1.size() - at;  // extends the previous formatted piece
+        } else {
+            fixups.emplace_back(b.iov1.size(), at);
+            b.iov1.push_back({nullptr, b.out1.size() - at});
+        }
+        last_formatted = true;
+    }
+    for (auto &f : fixups) b.iov1[f.first].iov_base = b.out1.data() + f.second;
+    return st;
+}
+
 // Output file written through a shared mapping: the formatter threads copy kept records to their final place in
 // parallel (a single write(2) stream moves ~6 GB/s and was the last serial stage).  The file is first sized to an
 // upper bound (sparse), and cut to the bytes really written at the end.
@@ -922,11 +1017,15 @@ int run_filter(const FilterArgs &a) {
     // ... and if the output is a plain file too, the formatter threads write it through a shared mapping
     MappedOutput mapped_out;
     const bool plain_out = a.output != "-" && !ends_with(a.output, ".gz") && !ends_with(a.output, ".zst") && !ends_with(a.output, ".xz");
-    if (parallel_in && plain_out && !std::getenv("DCN_CLI_NO_MMAP_OUT"))
+    // (DCN_CLI_MMAP_OUT=1; off by default: populating a tmpfs mapping from many threads contends in the kernel and
+    // ends up slower than one gather-writing thread, profiles/r02_cli_bench.txt)
+    if (parallel_in && plain_out && std::getenv("DCN_CLI_MMAP_OUT"))
         mapped_out.open(a.output, 5 * (uint64_t)mapped.size + (1u << 20));  // >= any formatted size (renamed ids: <= 20 digits)
     const bool map_out = mapped_out.active();
     std::unique_ptr<Output> out1_holder;
     if (!map_out) out1_holder.reset(new Output(a.output, a.compression_level));
+    // plain single-file output: the formatter only lists what to write, the writer thread gathers it with writev
+    const bool gather_out = !map_out && out1_holder->plain() && !(a.has_output2 && paired) && !std::getenv("DCN_CLI_NO_GATHER");
     std::unique_ptr<Output> out2;
     if (a.has_output2 && paired) out2.reset(new Output(a.output2, a.compression_level));
     else if (a.has_output2 && !quiet) std::fprintf(stderr, "Warning: --output2 specified but no second input file provided. --output2 will be ignored.\n");
@@ -1039,7 +1138,8 @@ int run_filter(const FilterArgs &a) {
     OrderedStage format_stage(parallel_in ? n_workers : 2, 2 * n_workers + 2, [&](Batch &b) {
         StageClock::Scope sc(t_format);
         BatchStats st = map_out ? format_batch_mapped(b, a.rename, b.seq_no, mapped_out.at(b.out_off, b.out_bytes), b.out_bytes)
-                                : format_batch(b, a.rename, split_mates, b.seq_no /* rename base, set by the GPU stage */);
+                        : gather_out ? format_batch_gather(b, a.rename, b.seq_no)
+                                     : format_batch(b, a.rename, split_mates, b.seq_no /* rename base, set by the GPU stage */);
         std::lock_guard<std::mutex> l(stats_m);
         tot.total_seqs += st.total_seqs;
         tot.filtered_seqs += st.filtered_seqs;
@@ -1053,6 +1153,10 @@ int run_filter(const FilterArgs &a) {
         while (format_stage.pop(b)) {
             if (map_out) continue;  // already in place
             StageClock::Scope sc(t_write);
+            if (gather_out) {
+                out1_holder->write_gather(b->iov1);
+                continue;
+            }
             out1_holder->write(b->out1);
             if (out2) out2->write(b->out2);
         }

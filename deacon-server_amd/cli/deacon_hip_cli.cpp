@@ -599,6 +599,10 @@ size_t next_record_start(const char *d, size_t size, size_t from, bool fastq) {
 // parse the records in [a, b) of the mapped file into batch (ids / qualities stay in the mapping)
 void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
     out.ext = d;
+    // one allocation each instead of the doubling growth of push_back / insert (which copied every base ~twice)
+    out.bases.reserve((b - a) / (fastq ? 2 : 1) + 64);
+    out.recs.reserve((b - a) / 192 + 16);
+    out.offsets.reserve((b - a) / 192 + 17);
     size_t p = a;
     auto trim = [&](size_t s0, size_t e) { return (e > s0 && d[e - 1] == '\r') ? e - 1 : e; };
     while (p < b) {
@@ -733,14 +737,8 @@ BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base
     const size_t per_unit = b.paired ? 2 : 1;
     uint64_t counter = rename_base;
     char *o = dst;
-    // the mapping's pages do not exist yet: one madvise for the batch instead of a fault per page
-    static const bool populate = !std::getenv("DCN_CLI_NO_POPULATE");
-#ifdef MADV_POPULATE_WRITE
-    if (populate && expect) {
-        const uintptr_t pa = (uintptr_t)dst & ~(uintptr_t)4095, pb = ((uintptr_t)dst + expect + 4095) & ~(uintptr_t)4095;
-        (void)madvise((void *)pa, pb - pa, MADV_POPULATE_WRITE);  // best effort (older kernels: EINVAL, pages fault in as before)
-    }
-#endif
+    // (MADV_POPULATE_WRITE over the batch's range before copying was measured slower than plain first-touch faults:
+    // 0.96 vs 0.80 s for 2.5 GB on tmpfs, profiles/r02_cli_bench.txt)
     uint64_t run_off = 0, run_len = 0;  // pending verbatim run in the input mapping
     auto flush_run = [&] {
         if (run_len) std::memcpy(o, chars + run_off, run_len), o += run_len, run_len = 0;
@@ -1017,9 +1015,9 @@ int run_filter(const FilterArgs &a) {
     // ... and if the output is a plain file too, the formatter threads write it through a shared mapping
     MappedOutput mapped_out;
     const bool plain_out = a.output != "-" && !ends_with(a.output, ".gz") && !ends_with(a.output, ".zst") && !ends_with(a.output, ".xz");
-    // (DCN_CLI_MMAP_OUT=1; off by default: populating a tmpfs mapping from many threads contends in the kernel and
-    // ends up slower than one gather-writing thread, profiles/r02_cli_bench.txt)
-    if (parallel_in && plain_out && std::getenv("DCN_CLI_MMAP_OUT"))
+    // (one write(2) / writev(2) stream moves 4.8-6.6 GB/s on tmpfs and stalls the stages in front of it: 0.90-0.95 s
+    // against 0.68-0.76 s through the mapping for the same 5 GB input, profiles/r02_cli_bench.txt)
+    if (parallel_in && plain_out && !std::getenv("DCN_CLI_NO_MMAP_OUT"))
         mapped_out.open(a.output, 5 * (uint64_t)mapped.size + (1u << 20));  // >= any formatted size (renamed ids: <= 20 digits)
     const bool map_out = mapped_out.active();
     std::unique_ptr<Output> out1_holder;

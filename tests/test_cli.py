@@ -491,17 +491,18 @@ def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
         out = run("filter", idx, tmp_path / name, "-t", 6).stdout
         got = [l[1:].rstrip(b"\r").decode() for l in out.split(b"\n")[0::4] if l]
         assert got == want, name
-        # three ways to the same bytes: the gather writer (default for plain output: ranges of the mapped input where a
-        # record already has its output form, formatted pieces otherwise, one writev per 1024 of them), the copying
-        # formatter (DCN_CLI_NO_GATHER), and the shared output mapping (DCN_CLI_MMAP_OUT)
+        # three ways to the same bytes: the shared output mapping (default for a plain file from a plain file: kept
+        # records copied to their final place by the formatter threads), the gather writer (pipes / stdout: ranges of
+        # the mapped input where a record already has its output form, formatted pieces otherwise, one writev per
+        # 1024 of them) and the copying formatter + write (compressed outputs; DCN_CLI_NO_GATHER)
         for extra in ([], ["-R"]):
+            run("filter", idx, tmp_path / name, "-t", 6, "-o", tmp_path / "mapped.fq", *extra)
+            monkeypatch.setenv("DCN_CLI_NO_MMAP_OUT", "1")
             run("filter", idx, tmp_path / name, "-t", 6, "-o", tmp_path / "gathered.fq", *extra)
             monkeypatch.setenv("DCN_CLI_NO_GATHER", "1")
             run("filter", idx, tmp_path / name, "-t", 6, "-o", tmp_path / "streamed.fq", *extra)
             monkeypatch.delenv("DCN_CLI_NO_GATHER")
-            monkeypatch.setenv("DCN_CLI_MMAP_OUT", "1")
-            run("filter", idx, tmp_path / name, "-t", 6, "-o", tmp_path / "mapped.fq", *extra)
-            monkeypatch.delenv("DCN_CLI_MMAP_OUT")
+            monkeypatch.delenv("DCN_CLI_NO_MMAP_OUT")
             assert (tmp_path / "gathered.fq").read_bytes() == (tmp_path / "streamed.fq").read_bytes(), (name, extra)
             assert (tmp_path / "mapped.fq").read_bytes() == (tmp_path / "streamed.fq").read_bytes(), (name, extra)
             if not extra:
@@ -510,12 +511,9 @@ def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
     fa = b"".join((b">s%d d\n%s\n" % (i, r)) if i % 2 else (b">s%d d\n%s\n%s\n" % (i, r[:30], r[30:])) for i, r in enumerate(reads[:5000]))
     (tmp_path / "in.fa").write_bytes(fa)
     out = run("filter", idx, tmp_path / "in.fa").stdout
-    run("filter", idx, tmp_path / "in.fa", "-o", tmp_path / "gathered.fa")
-    assert (tmp_path / "gathered.fa").read_bytes() == out
-    assert [l[1:].decode() for l in out.split(b"\n")[0::2] if l] == [f"s{i} d" for i in range(5000) if keep[i]]
-    monkeypatch.setenv("DCN_CLI_MMAP_OUT", "1")
     run("filter", idx, tmp_path / "in.fa", "-o", tmp_path / "mapped.fa")
     assert (tmp_path / "mapped.fa").read_bytes() == out
+    assert [l[1:].decode() for l in out.split(b"\n")[0::2] if l] == [f"s{i} d" for i in range(5000) if keep[i]]
     # nothing kept: an empty file, not the reservation
     run("filter", idx, tmp_path / "in.fa", "-a", 60000, "-o", tmp_path / "none.fa")
     assert (tmp_path / "none.fa").stat().st_size == 0

@@ -110,6 +110,10 @@ template <int N>
 struct IntTag {
     static constexpr int value = N;
 };
+#ifndef DCN_PIPE_B
+#define DCN_PIPE_B 0 // 1: phase B software-pipelined by one round (the next round's owner search and sequence / mask loads
+                     // are issued between this round's set probe and its use); needs DCN_U_FINAL == 1
+#endif
 #ifndef DCN_U_FINAL
 #define DCN_U_FINAL 1 // items per lane per phase-B group in the final flush (measured 1..8: 1 is best)
 #endif
@@ -226,6 +230,58 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
         }
         __syncthreads();
         constexpr int NPW = K128 ? 5 : 3; // packed words per k-mer
+        constexpr bool PIPE = DCN_PIPE_B && U == 1;
+        // one item per lane, everything up to and including its sequence / mask loads (the pipelined form issues this for
+        // round r+1 while round r's set probe is in flight)
+        struct Item {
+            bool act;
+            uint32_t lo, idx, rel, o_uslot;
+            uint64_t p;
+            uint32_t mw[3], pw[NPW];
+        };
+        auto fetch = [&](uint32_t E, Item &it) {
+            const uint32_t e = E + lane;
+            it.act = e < M;
+            uint32_t l_ = 0, h_ = 63;
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                const uint32_t mid = (l_ + h_ + 1) >> 1;
+                const bool le = sh.start[mid] <= e;
+                l_ = le ? mid : l_;
+                h_ = le ? h_ : mid - 1;
+            }
+            it.lo = l_;
+            it.idx = it.act ? e - sh.start[l_] : 0;
+            const uint32_t o_skip = __shfl(skip0, l_, 64);
+#ifdef DCN_DEBUG_BOUNDS
+            if (it.act && (l_ > 63u || it.idx + o_skip >= (uint32_t)DCN_LCAP + 2u)) {
+                a.status->bounds = 1;
+                it.act = false;
+                it.idx = 0;
+            }
+#endif
+            it.rel = sh.DCN_LIST_AT(l_, it.idx + o_skip);
+            const long long o_s = __shfl((long long)s, l_, 64);
+            it.o_uslot = __shfl(uslot, l_, 64);
+            it.p = (uint64_t)(o_s + it.rel);
+#ifdef DCN_DEBUG_BOUNDS
+            if (it.act && it.p + k > a.stream_bases) {
+                a.status->bounds = 2;
+                it.act = false;
+                it.p = 0;
+            }
+#endif
+            if (it.act) {
+                const uint32_t *mp = a.invmask + (it.p >> 5);
+                const uint32_t *pp = packed + (it.p >> 4);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) it.mw[q] = mp[q];
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) it.pw[q] = pp[q];
+            }
+        };
+        Item cur, nxt;
+        if (PIPE && M) fetch(0, cur);
         for (uint32_t E = 0; E < ((DCN_EXP & 2) ? 0u : M); E += DCN_WAVE * U) {
             bool act[U];
             uint32_t lo[U], hi[U];
@@ -236,6 +292,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 hi[u] = 63;
             }
             // owner = largest lane whose list starts at or before e (6 steps, the U searches interleaved)
+            if (!PIPE) {
 #pragma unroll
             for (int it = 0; it < 6; ++it) {
 #pragma unroll
@@ -247,10 +304,24 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     hi[u] = le ? hi[u] : mid - 1;
                 }
             }
+            }
             uint64_t p[U];
             uint32_t o_uslot[U], idx[U], rel[U];
+            uint32_t mw[U][3], pw[U][NPW];
+            if (PIPE) {
+                act[0] = cur.act;
+                lo[0] = cur.lo;
+                idx[0] = cur.idx;
+                rel[0] = cur.rel;
+                o_uslot[0] = cur.o_uslot;
+                p[0] = cur.p;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+                for (int q = 0; q < 3; ++q) mw[0][q] = cur.mw[q];
+#pragma unroll
+                for (int q = 0; q < NPW; ++q) pw[0][q] = cur.pw[q];
+            }
+#pragma unroll
+            for (int u = 0; u < (PIPE ? 0 : U); ++u) {
                 uint32_t e = E + u * DCN_WAVE + lane;
                 idx[u] = act[u] ? e - sh.start[lo[u]] : 0;
                 uint32_t o_skip = __shfl(skip0, lo[u], 64);
@@ -276,9 +347,8 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 }
 #endif
             }
-            uint32_t mw[U][3], pw[U][NPW];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < (PIPE ? 0 : U); ++u) {
                 if (act[u]) {
                     const uint32_t *mp = a.invmask + (p[u] >> 5);
                     const uint32_t *pp = packed + (p[u] >> 4);
@@ -325,6 +395,10 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         a.dump_valid[slot] = valid[u] ? 1 : 0;
                     }
                 }
+                if (PIPE) {
+                    if (E + DCN_WAVE < M) fetch(E + DCN_WAVE, nxt);
+                    cur = nxt;
+                }
                 continue;
             }
             // set membership: one 32-byte group per item, the U loads in flight together; walking on to the next
@@ -336,6 +410,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 grp[u] = dcn_group_of(hash[u], a.table.group_shift, a.table.group_mask);
                 if (valid[u] && !(DCN_EXP & 1)) g[u] = dcn_load_group(a.table, grp[u]);
             }
+            if (PIPE && E + DCN_WAVE < M) fetch(E + DCN_WAVE, nxt); // behind the probe, ahead of its use
             bool hit[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -437,6 +512,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     }
                 }
             }
+            if (PIPE) cur = nxt;
         }
         if (!DUMP && cnt_eff) atomicAdd(&sh.total[uslot], cnt_eff); // invalid ones were subtracted above
         emitted_before += cnt_eff;

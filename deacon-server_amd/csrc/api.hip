@@ -373,7 +373,8 @@ struct dcn_ctx {
     // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
     // units whose hits do not fit the LDS set of the distinct pass (4 slots per record of capacity)
     uint64_t *d_rec_hash = nullptr;
-    uint32_t *d_tile_hits = nullptr, *d_pending = nullptr, *d_big = nullptr;
+    uint32_t *d_tile_hits = nullptr, *d_pending = nullptr;
+    uint2 *d_big = nullptr; // work items of the distinct pass B: at most one per 64 tiles + one per unit
     uint64_t rec_capacity = 0;
     uint64_t *d_set_slots = nullptr;
     dcn_status *d_status = nullptr;
@@ -1013,7 +1014,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_set_off, MR + 1, "set_off");
     A(d_tile_hits, mt, "tile_hits");
     A(d_pending, MR, "pending");
-    A(d_big, MR, "big");
+    A(d_big, MR + mt / 64 + 1, "big");
     A(d_rec_hash, max_batch_bases + 64, "rec_hash");
     A(d_status, 1, "status");
     A(d_report, 1, "report");

@@ -94,7 +94,7 @@ struct dcn_status {
     uint32_t rec_overflow;         // the global hash sets of the distinct pass did not fit their scratch
     uint32_t n_tiles;
     uint32_t any_records;          // the scan wrote a hit into some tile's run: the distinct pass has work
-    uint32_t n_big;                // units with more hits than the LDS set holds: the global-set kernels have work
+    uint32_t n_big;                // work items of units with more hits than the LDS set holds (one per 64 tiles)
     uint32_t any_scattered;        // ... one of them with tiles that are not contiguous (found by a sweep over all tiles)
     uint32_t n_pending;            // units enrolled for the distinct pass (scan.hip)
     uint32_t any_newline;          // the pack kernel saw a '\n' byte: only then does planning probe read ends

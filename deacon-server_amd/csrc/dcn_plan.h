@@ -38,7 +38,7 @@ struct dcn_distinct_args {
     uint32_t *g_distinct;
     uint32_t *set_off; // n_units: first slot of a unit's global set (only for units with caps != 0)
     uint32_t *caps;    // n_units: global set size (power of two), 0 = none (counted in LDS, or no hits)
-    uint32_t *big;     // work list of the units with a global set (status->n_big of them)
+    uint2 *big;        // pass B's work items: (unit, first of 64 tiles), status->n_big of them
     uint64_t *set_slots;
     uint64_t set_capacity;
     uint32_t n_units;

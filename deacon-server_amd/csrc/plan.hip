@@ -157,8 +157,11 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
 // global atomics at all, which is where the old (unit, hash) CAS pass spent 0.64 ms per 600 Mbp of long reads.  A
 // larger unit (a long read from the indexed genome) gets a region of the global set scratch instead, so that pass B
 // can spread its runs over the whole chip.
-constexpr uint32_t DCN_LDS_SET_SLOTS = 2048; // 16 KB: ten waves per CU
-constexpr uint32_t DCN_LDS_SET_MAX = 1400;   // hits deduplicated in LDS (load <= 0.68)
+#ifndef DCN_LDS_SET_LOG2
+#define DCN_LDS_SET_LOG2 11 // 2048 slots = 16 KB: ten waves per CU (12 = 32 KB measured in profiles/r02_ab.txt)
+#endif
+constexpr uint32_t DCN_LDS_SET_SLOTS = 1u << DCN_LDS_SET_LOG2;
+constexpr uint32_t DCN_LDS_SET_MAX = DCN_LDS_SET_SLOTS * 7 / 10 - 33; // hits deduplicated in LDS (load <= 0.68): 1400 for 2048 slots
 
 __device__ inline uint32_t set_slot_of(uint64_t h, uint32_t cap) {
     uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
@@ -188,43 +191,51 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
             continue;
         }
         if (count == 0xFFFFFFFFu || H > DCN_LDS_SET_MAX) {
-            // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor.  Pass B clears the
-            // region of a unit it owns as a workgroup; a scattered unit's region is filled by waves all over the
-            // grid, so it is cleared here
+            // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor (all regions are
+            // cleared by one small kernel between the passes)
             uint32_t cap = 64;
             while (cap < 2u * H && cap < (1u << 31)) cap <<= 1;
             unsigned long long off = 0;
             if (lane == 0) off = atomicAdd(&a.status->set_cursor, (unsigned long long)cap);
             off = (unsigned long long)__shfl((long long)off, 0, 64);
             const bool fits = off + cap <= a.set_capacity;
+            // work items of pass B: one per 64 tiles of the unit (a run hangs on the first tile a scan wave held, so a
+            // slice holds one or two runs), which spreads a chromosome-sized read over as many waves as it has runs
+            const uint32_t n_items = count == 0xFFFFFFFFu ? 0u : (count + 63) / 64;
+            uint32_t item0 = 0;
             if (lane == 0) {
                 a.set_off[u] = (uint32_t)off;
                 a.caps[u] = fits ? cap : 0u;
                 if (!fits) a.status->rec_overflow = 1;
-                else a.big[atomicAdd(&a.status->n_big, 1u)] = u;
+                else if (n_items) item0 = atomicAdd(&a.status->n_big, n_items);
                 if (fits && count == 0xFFFFFFFFu) a.status->any_scattered = 1;
             }
-            if (fits && count == 0xFFFFFFFFu) {
-                for (uint32_t q = lane; q < cap; q += 64) a.set_slots[off + q] = 0;
-                __threadfence();
-            }
+            item0 = __shfl(item0, 0, 64);
+            if (fits)
+                for (uint32_t q = lane; q < n_items; q += 64) a.big[item0 + q] = make_uint2(u, 64 * q);
             continue;
         }
         uint32_t cap = 64;
         while (cap < 2u * H) cap <<= 1;
         if (cap > DCN_LDS_SET_SLOTS) cap = DCN_LDS_SET_SLOTS;
-        for (uint32_t q = lane; q < cap; q += 64) set[q] = 0;
-        __syncthreads();
-        uint32_t distinct = 0;
-        for (uint32_t t0 = 0; t0 < count; t0 += 64) {
-            const uint32_t t = t0 + lane;
-            uint32_t n = 0;
-            uint64_t slot0 = 0;
-            if (t < count) { // both loads issued together
+        // the unit's first 64 tiles (usually all of them): both loads in flight while the set is cleared
+        auto tile_run = [&](uint32_t t, uint32_t &n, uint64_t &slot0) {
+            n = 0;
+            slot0 = 0;
+            if (t < count) {
                 n = a.tile_hits[first + t];
                 const dcn_tile tl = a.tiles[first + t];
                 slot0 = tl.scan_start + (tl.flags & 1u);
             }
+        };
+        uint32_t n;
+        uint64_t slot0;
+        tile_run(lane, n, slot0);
+        for (uint32_t q = lane; q < cap; q += 64) set[q] = 0;
+        __syncthreads();
+        uint32_t distinct = 0;
+        for (uint32_t t0 = 0; t0 < count; t0 += 64) {
+            if (t0) tile_run(t0 + lane, n, slot0);
             unsigned long long runs = __ballot(n != 0);
             while (runs) { // one or two per unit: a run per wave that held tiles of it
                 const int r = __ffsll((long long)runs) - 1;
@@ -305,45 +316,48 @@ __device__ inline uint32_t insert_run(const uint64_t *rec_hash, uint64_t slot0, 
     return fresh_n;
 }
 
-// Pass B, one workgroup per unit with a global set: clear the unit's region, then its waves share the unit's tiles
-// (64 per step), find the runs hanging on them and CAS-insert those; one atomicAdd of the number of new keys per
-// wave.  Units whose tiles are not contiguous in the tile array (a unit of three or more reads cut by a planning
-// block; never a single read or a pair) have no tile list: if there is one, every tile of the batch is looked at.
+__global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, const dcn_status *status) {
+    if (status->set_cursor == 0 || status->rec_overflow) return;
+    uint64_t total = status->set_cursor;
+    if (total > capacity) total = capacity;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) set_slots[i] = 0;
+}
+
+// Pass B, one wave per work item (64 consecutive tiles of a unit with a global set): find the runs hanging on those
+// tiles and CAS-insert them; one atomicAdd of the number of new keys per wave.  Units whose tiles are not contiguous
+// in the tile array (a unit of three or more reads cut by a planning block; never a single read or a pair) have no
+// tile list: if there is one, every tile of the batch is looked at.
 __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
+    if (a.status->set_cursor == 0 || a.status->rec_overflow) return;
     const uint32_t NB = a.status->n_big;
-    if (NB == 0 || a.status->rec_overflow) return;
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t bi = blockIdx.x; bi < NB; bi += gridDim.x) {
-        const uint32_t u = a.big[bi];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t bi = gwave; bi < NB; bi += n_waves) {
+        const uint2 item = a.big[bi];
+        const uint32_t u = item.x;
         const uint32_t first = a.unit_tile_first[u], count = a.unit_tile_count[u];
-        if (count == 0xFFFFFFFFu) continue; // below
         const uint32_t cap = a.caps[u];
         unsigned long long *region = (unsigned long long *)(a.set_slots + a.set_off[u]);
-        for (uint32_t q = threadIdx.x; q < cap; q += blockDim.x) region[q] = 0;
-        __threadfence();
-        __syncthreads();
+        const uint32_t t = item.y + lane;
+        uint32_t n = 0;
+        uint64_t slot0 = 0;
+        if (t < count) {
+            n = a.tile_hits[first + t];
+            const dcn_tile tl = a.tiles[first + t];
+            slot0 = tl.scan_start + (tl.flags & 1u);
+        }
         uint32_t fresh_n = 0;
-        for (uint32_t t0 = wave * 64; t0 < count; t0 += 256) {
-            const uint32_t t = t0 + lane;
-            uint32_t n = 0;
-            uint64_t slot0 = 0;
-            if (t < count) {
-                n = a.tile_hits[first + t];
-                const dcn_tile tl = a.tiles[first + t];
-                slot0 = tl.scan_start + (tl.flags & 1u);
-            }
-            unsigned long long runs = __ballot(n != 0);
-            while (runs) {
-                const int r = __ffsll((long long)runs) - 1;
-                runs &= runs - 1;
-                fresh_n += insert_run(a.rec_hash, (uint64_t)__shfl((long long)slot0, r, 64), __shfl(n, r, 64), region, cap, lane);
-            }
+        unsigned long long runs = __ballot(n != 0);
+        while (runs) {
+            const int r = __ffsll((long long)runs) - 1;
+            runs &= runs - 1;
+            fresh_n += insert_run(a.rec_hash, (uint64_t)__shfl((long long)slot0, r, 64), __shfl(n, r, 64), region, cap, lane);
         }
         if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[u], fresh_n);
     }
     if (a.status->any_scattered == 0) return;
     const uint32_t NT = *a.n_tiles;
-    const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t t = gwave; t < NT; t += n_waves) {
         const dcn_tile tl = a.tiles[t];
         if (a.unit_state[tl.unit] || a.unit_tile_count[tl.unit] != 0xFFFFFFFFu) continue;
@@ -483,6 +497,7 @@ int dcn_launch_plan(const dcn_plan_args &a, hipStream_t stream) {
 
 int dcn_launch_distinct(const dcn_distinct_args &a, hipStream_t stream) {
     hipLaunchKernelGGL(unit_distinct_kernel, dim3(std::max(1u, std::min(a.n_units, 256u * 10u))), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(distinct_clear_kernel, dim3(1024), dim3(256), 0, stream, a.set_slots, a.set_capacity, a.status);
     hipLaunchKernelGGL(big_insert_kernel, dim3(2048), dim3(256), 0, stream, a);
     DCN_HIP(hipGetLastError());
     return DCN_OK;

@@ -574,3 +574,30 @@ def test_properties_at_scale(oracle, dcn, genome, index_pair):
     sl = slice(200_000, 203_000)
     want = oracle.filter_batch(oidx, bases[sl.start * 150:sl.stop * 150], offsets[:3001], threads=4)
     assert want[1].tolist() == hits[sl].tolist() and want[2].tolist() == total[sl].tolist()
+
+
+def test_units_of_many_reads_cut_by_a_planning_block(oracle, dcn, genome, index_pair):
+    """unit_id may group any number of consecutive reads.  A unit whose reads fall into two planning blocks (256 reads
+    each) has no contiguous tile range: the scan cannot finish it in-wave, and the distinct pass finds its tiles by
+    sweeping all of them -- with an LDS-sized hit count (never: such units always take a global set) and with
+    thousands of hits (long exact reads)."""
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(60)
+    reads = sample_reads(rng, genome, 254, 40, 200)
+    uid = list(range(254))
+    # unit 254: five long reads from the genome, reads 254..258 -> cut by the block boundary at read 256
+    for j in range(5):
+        reads.append(genome[j * 30_000:j * 30_000 + 25_000])
+        uid.append(254)
+    # unit 255: three short reads right after it; unit 256..: singles again, and one more cut unit at the next boundary
+    more = sample_reads(rng, genome, 253 + 40, 40, 200)
+    reads += more
+    uid += [255, 255, 255] + list(range(256, 256 + 248)) + [600] * 6 + list(range(601, 601 + 36))
+    uid = np.array(uid, dtype=np.uint32)
+    uid = np.cumsum(np.concatenate([[0], (np.diff(uid) != 0).astype(np.uint32)])).astype(np.uint32)  # 0,1,2,... without gaps
+    assert len(uid) == len(reads)
+    for deplete, abs_t in ((False, 2), (True, 40)):
+        proc = dcn.FilterProcessor(gidx, abs_threshold=abs_t, deplete=deplete, max_batch_bases=1 << 20, max_batch_reads=1 << 10)
+        keep, hits, total = check_batch(oracle, proc, oidx, reads, uid)
+        assert hits[254] > 5000  # the cut unit went through the global-set path
+        proc.close()

@@ -1,7 +1,11 @@
-"""Worker of tests/test_distributed.py (launched with torch.distributed.run, backend gloo, CPU only).
+"""Worker of tests/test_distributed.py (launched with torch.distributed.run, backend gloo).
 
-There is no GPU here, so the per-batch filter engine is the CPU oracle standing in for FilterProcessor.filter_batch
-(same inputs, same outputs); what is under test is the N>1 host logic of deacon-server_amd/distributed.py."""
+Without a GPU (argv[2] absent) the per-batch filter engine is the CPU oracle standing in for
+FilterProcessor.filter_batch (same inputs, same outputs): what is under test is the N>1 host logic of
+deacon-server_amd/distributed.py.  With argv[2] == "gpu" (the -m gpu test) every rank runs the REAL engine -- its
+own index replica and FilterProcessor on GPU 0 of the one-GPU box -- and takes its counters from dcn_ctx_stats;
+the collectives stay on gloo (RCCL refuses two ranks on one device), which is the only thing that differs from
+bench.py's N>1 run."""
 import json
 import os
 import sys
@@ -19,6 +23,9 @@ from oracle import oracle as O  # noqa: E402
 
 def main():
     out_path = sys.argv[1]
+    on_gpu = len(sys.argv) > 2 and sys.argv[2] == "gpu"
+    if on_gpu:
+        import torch  # noqa: F401  (its HIP runtime first, as everywhere)
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     rng = np.random.default_rng(123)  # same data on every rank
@@ -39,11 +46,19 @@ def main():
     mine = dcn.distributed.batches_of_rank(len(batches), rank, world)
     stats = {n: 0 for n in dcn._native.STAT_NAMES}
     local = {}
+    proc = None
+    if on_gpu:
+        gidx = dcn.Index.from_keys(idx.keys(), 31, 15, device=0)  # this rank's replica
+        proc = dcn.FilterProcessor(gidx, deplete=True, max_batch_bases=1 << 20, max_batch_reads=1 << 12)
     for seq in mine:
         a, b = batches[seq]
         sel = [r for r in range(len(reads)) if a <= uid[r] < b]
         sub = [reads[r] for r in sel]
         bases, offsets = O.concat_reads(sub)
+        if on_gpu:
+            keep, hits, total = proc.filter_batch(bases, offsets, (uid[sel] - a).astype(np.uint32))
+            local[seq] = keep
+            continue
         keep, hits, total = O.filter_batch(idx, bases, offsets, (uid[sel] - a).astype(np.uint32), deplete=True)
         local[seq] = keep
         for u in range(b - a):
@@ -57,6 +72,8 @@ def main():
             else:
                 stats["filtered_seqs"] += len(rs)
                 stats["filtered_bp"] += bp
+    if on_gpu:
+        stats = proc.stats()  # the engine's own six counters
     total_stats = dcn.distributed.allreduce_counters(stats)
     keep_all = dcn.distributed.gather_keep_in_order(local, n_units, batch_units)
     if rank == 0:

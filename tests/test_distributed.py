@@ -39,3 +39,18 @@ def test_two_ranks_gloo(tmp_path, world):
     assert res["world"] == world and res["n_batches"] == 16
     assert res["stats"] == res["want"]
     assert res["keep_equal"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_the_gpu_engine(tmp_path):
+    """the same job with the real engine on every rank (two processes sharing GPU 0, own replica + context each,
+    counters from dcn_ctx_stats): decisions in input order and the all-reduced counters equal the single-process
+    oracle's.  gloo carries the collectives (RCCL does not take two ranks on one device)."""
+    out = tmp_path / "result.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), "gpu"]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    res = json.load(open(out))
+    assert res["world"] == 2 and res["stats"] == res["want"] and res["keep_equal"]

@@ -261,9 +261,10 @@ def host_cores():
 
 
 # ---- the device-resident measurement ---------------------------------------------------------------------------------
-def run_device_workload(index, batches, params, steps, warmup, world, device, reserve_long=False, timed_hook=None):
+def run_device_workload(index, batches, params, steps, warmup, world, device, reserve_long=False, coll_device=None):
     """K steps over the rotating batches, counting mode (keep + distinct hits + totals), then the same K steps asking
     for decisions only.  Returns (result dict, counters of the timed region)."""
+    coll_device = device if coll_device is None else coll_device
     max_bases = max(b.n_bases for b in batches)
     max_reads = max(b.n_reads for b in batches)
     proc = dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"], deplete=params["deplete"],
@@ -293,12 +294,12 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
         proc.synchronize()
         local = proc.stats()
         # RCCL all-reduce of the six counters: the path's only collective
-        counters = dcn.distributed.allreduce_counters(local, device=device)
+        counters = dcn.distributed.allreduce_counters(local, device=coll_device)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms, nb = proc.profile()
@@ -549,11 +550,20 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # rehearsal of the N > 1 path on a one-GPU box (profiles/rehearse_two_ranks.sh): every rank on GPU 0, collectives
+    # on gloo (RCCL does not take two ranks on one device).  The driver's scaling run uses neither variable.
+    backend = os.environ.get("DCN_BENCH_BACKEND", "nccl")
+    if os.environ.get("DCN_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- index: host-genome minimizers + mix64 keys, identical on every rank ------------------------------------
     genome_dev = make_host_genome(args.host_genome, 3, device)
@@ -569,7 +579,7 @@ def main():
     log(f"{args.workload}: {len(batches)} batches of {batches[0].n_reads:,} reads / {batches[0].n_bases / 1e6:.0f} Mbp resident in HBM")
 
     head, counters, elapsed, bases_done = run_device_workload(index, batches, params, args.steps, args.warmup, world, device,
-                                                              reserve_long=args.workload == "long")
+                                                              reserve_long=args.workload == "long", coll_device=coll_device)
     if rank == 0:
         total_bp = counters["total_bp"]
         if args.workload != "long" or world == 1:  # long reads: every rank draws its own lengths

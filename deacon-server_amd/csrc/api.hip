@@ -1025,6 +1025,8 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     if (const char *rc_env = getenv("DCN_RECORD_CAPACITY")) recs = std::min<uint64_t>(std::max<uint64_t>(strtoull(rc_env, nullptr, 10), 64), 1ull << 29); // tests: force the growth path
     if ((rc = alloc_records(c, recs)) != DCN_OK) return fail(rc);
     c->stage_bytes = std::min<uint64_t>(std::max<uint64_t>(max_batch_bases + 64, 4096), 32ull << 20);
+    if (const char *sb = getenv("DCN_STAGE_BYTES")) // tests: small staging buffers, so that one chunk needs many pieces
+        c->stage_bytes = std::min<uint64_t>(std::max<uint64_t>(strtoull(sb, nullptr, 10), 4096), 32ull << 20);
     for (int i = 0; i < dcn_ctx::N_STAGE; ++i)
         if (hipHostMalloc((void **)&c->h_stage[i], c->stage_bytes, hipHostMallocDefault) != hipSuccess)
             return fail(dcn_fail(DCN_ERR_NOMEM, "pinned staging allocation failed"));
@@ -1285,7 +1287,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         if (n_bases > 0 && !packed_in && !in.bases) return dcn_fail(DCN_ERR_ARG, "bases is NULL");
         if (n_bases > 0 && packed_in && !in.invmask) return dcn_fail(DCN_ERR_ARG, "invmask is NULL");
     }
-    static const bool host_pack_ok = !getenv("DCN_NO_HOST_PACK");
+    const bool host_pack_ok = !getenv("DCN_NO_HOST_PACK"); // read per call: tests switch it
     Transport tr;
     if (in.packed) tr = Transport::Packed;
     else if (is_pinned_host(in.bases)) tr = Transport::AsciiDirect;

@@ -79,6 +79,32 @@ def test_chunked_batch_matches_oracle(oracle, dcn, genome, index_pair, monkeypat
     proc.close()
 
 
+@pytest.mark.parametrize("host_pack", [True, False])
+def test_small_staging_ring_many_pieces_per_chunk(oracle, dcn, genome, index_pair, monkeypatch, host_pack):
+    """pageable input through 8 KB staging buffers: every chunk's payload (host-packed stream + mask, or ASCII with
+    DCN_NO_HOST_PACK), offsets and unit ids pass through the three-buffer ring in dozens of pieces, the ring wraps
+    many times, and two batches in flight share it"""
+    small_chunks(monkeypatch, 150_000)
+    monkeypatch.setenv("DCN_STAGE_BYTES", "8192")
+    if not host_pack:
+        monkeypatch.setenv("DCN_NO_HOST_PACK", "1")
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(150 + host_pack)
+    reads = mixed_reads(rng, genome, 2000, 5)
+    b, o = oracle.concat_reads(reads)
+    uid = (np.arange(len(reads)) // 2).astype(np.uint32)
+    proc = dcn.FilterProcessor(gidx, deplete=True, max_batch_bases=len(b) + 64, max_batch_reads=len(reads))
+    want = oracle_batch(oracle, oidx, proc, b, o, uid)
+    want1 = oracle_batch(oracle, oidx, proc, b, o, None)
+    p1 = proc.submit(b, o, uid)
+    p2 = proc.submit(b, o, None)
+    assert_same(p1.wait(), want)
+    assert_same(p2.wait(), want1)
+    packed, mask = dcn.pack_ascii(b)
+    assert_same(proc.filter_batch_packed(packed, mask, o, uid), want)  # pageable packed input: staged piecewise too
+    proc.close()
+
+
 def test_submit_wait_two_in_flight(oracle, dcn, genome, index_pair, monkeypatch):
     small_chunks(monkeypatch, 50_000)
     oidx, gidx = index_pair

@@ -280,10 +280,20 @@ class MultiGpuFilter {
             by_device[d] = replicas_.back().raw();
         }
         for (std::size_t i = 0; i < devices.size(); ++i) workers_.emplace_back(new Worker());
+        // every context first, the threads only once nothing can throw any more (a constructor that throws with a
+        // thread already running would end in std::terminate)
         for (std::size_t i = 0; i < devices.size(); ++i) {
-            Worker *w = workers_[i].get();
-            check(dcn_ctx_create(by_device[devices[i]], config.max_batch_bases, config.max_batch_reads, &w->ctx));
-            w->thread = std::thread([this, w] { work(*w); });
+            int rc = dcn_ctx_create(by_device[devices[i]], config.max_batch_bases, config.max_batch_reads, &workers_[i]->ctx);
+            if (rc != DCN_OK) {
+                const std::string msg = std::string("deacon_hip error ") + std::to_string(rc) + ": " + dcn_last_error();
+                for (auto &w : workers_)
+                    if (w->ctx) dcn_ctx_destroy(w->ctx);
+                throw Error(rc, msg);
+            }
+        }
+        for (auto &w : workers_) {
+            Worker *wp = w.get();
+            wp->thread = std::thread([this, wp] { work(*wp); });
         }
     }
     MultiGpuFilter(const MultiGpuFilter &) = delete;

@@ -46,7 +46,7 @@
 
 namespace {
 
-const char *VERSION = "0.1.0";
+const char *VERSION = "0.2.0";
 
 std::atomic<int> g_sparse_out_fd{-1};  // output file still sized to its reservation (MappedOutput): cut on failure
 

@@ -26,7 +26,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#define DCN_VERSION_STRING "deacon-hip 0.1.0 (gfx950)"
+#define DCN_VERSION_STRING "deacon-hip 0.2.0 (gfx950)"
 
 // ----------------------------------------------------------------------------------------------------
 // errors

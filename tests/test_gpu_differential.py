@@ -61,7 +61,12 @@ def random_case(rng, genome):
 def test_differential(oracle, dcn, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     genome = random_reads(rng, 1, 60_000, 60_000)[0]
-    monkeypatch.setenv("DCN_TILE_WINDOWS", str(int(rng.choice([16, 64, 512, 512, 4096]))))
+    monkeypatch.setenv("DCN_TILE_WINDOWS", str(int(rng.choice([16, 64, 256, 512, 2048]))))
+    # host pipeline geometry: chunk seams anywhere in the batch, staging pieces from tiny to default
+    monkeypatch.setenv("DCN_CHUNK_BASES", str(int(rng.choice([1024, 5000, 40_000, 1 << 26]))))
+    monkeypatch.setenv("DCN_STAGE_BYTES", str(int(rng.choice([4096, 65536, 32 << 20]))))
+    if rng.random() < 0.3:
+        monkeypatch.setenv("DCN_NO_HOST_PACK", "1")
     indexes = {}
     for case in range(10):
         k, w, reads, uid, params = random_case(rng, genome)

@@ -1176,11 +1176,10 @@ int ensure_pinned(T **p, uint64_t count) {
 // in copy commands and launches than the shorter tail gives back.)  Found by bisection on offsets that have NOT been
 // validated yet (any answer in (r0, n_reads] is safe; validate_chunk runs while the
 // chunk's payload is already on its way).
-uint32_t find_cut(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t n_bases_total) {
+uint32_t find_cut(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t chunk_bases) {
     const uint64_t *off = in.offsets;
     const uint64_t b0 = off[r0];
-    (void)n_bases_total;
-    const uint64_t target = b0 + c->chunk_bases;
+    const uint64_t target = b0 + chunk_bases;
     uint32_t lo = r0 + 1, hi = in.n_reads; // smallest r in [lo, hi] with off[r] >= target, else n_reads
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
@@ -1323,6 +1322,10 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     const int off_pinned = is_pinned_host(in.offsets) ? 1 : 0, uid_pinned = is_pinned_host(in.unit_id) ? 1 : 0;
     const int pk_pinned = in.packed ? ((is_pinned_host(in.packed) && is_pinned_host(in.invmask)) ? 1 : 0) : 0;
 
+    // With another batch already in flight the kernels of this batch's last chunk are covered by the next batch's
+    // copies, so nothing argues for small chunks any more, and every chunk costs the host ~0.2 ms of runtime calls:
+    // twice the chunk size then (packed input, two in flight: 105 -> 120 Gbp/s when the host was the limit).
+    const uint64_t chunk_bases = c->chunk_bases * (slots_busy(c) ? 2 : 1);
     for (int attempt = 0;; ++attempt) {
         sl.device_pack = tr == Transport::AsciiDirect || tr == Transport::AsciiStaged;
         sl.chunks.clear();
@@ -1338,7 +1341,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
             dcn_chunk ch;
             ch.r0 = r0;
             ch.u0 = u0;
-            ch.r1 = find_cut(c, in, r0, n_bases);
+            ch.r1 = find_cut(c, in, r0, chunk_bases);
             ch.u1 = in.unit_id ? (ch.r1 == n_reads ? in.unit_id[n_reads - 1] + 1 : in.unit_id[ch.r1]) : ch.r1;
             ch.b0 = in.offsets[ch.r0];
             ch.b1 = in.offsets[ch.r1];

@@ -142,7 +142,12 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     const uint32_t carry = t.flags & 1u;
     const uint32_t nwc = t.n_windows ? t.n_windows + carry : 0; // windows this lane evaluates
     const uint32_t unit_prev = __shfl_up(t.unit, 1, 64);
-    const bool head = lane == 0 || t.unit != unit_prev;
+    const uint64_t start_prev = (uint64_t)__shfl_up((long long)t.scan_start, 1, 64);
+    // A unit slot is a run of adjacent lanes of one unit IN STREAM ORDER.  Tiles follow the stream inside a planning
+    // block's range, but the ranges of different blocks are placed in whatever order their cursor atomics ran: a unit
+    // of three or more reads cut by a block boundary can meet itself again with the later reads first.  Such a lane
+    // starts a new slot (and a new run of the record array: a run may only grow over windows that lie behind it).
+    const bool head = lane == 0 || t.unit != unit_prev || t.scan_start < start_prev;
     const unsigned long long head_mask = __ballot(head);
     const uint32_t uslot = (uint32_t)__popcll(head_mask & ((2ull << lane) - 1)) - 1;
     sh.total[lane] = 0;

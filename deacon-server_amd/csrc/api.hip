@@ -1263,6 +1263,12 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d) {
 }
 
 int finish_submission(dcn_ctx *c, dcn_slot &sl) {
+    // the report is written on the compute stream (cleared at submission, filled by the finish kernels): the copy must
+    // come behind all of it, also for a batch without any chunk
+    const int e = c->ev_next;
+    c->ev_next = (e + 1) % dcn_ctx::N_EV;
+    DCN_HIP(hipEventRecord(c->ev_comp[e], c->stream));
+    DCN_HIP(hipStreamWaitEvent(c->d2h_stream, c->ev_comp[e], 0));
     DCN_HIP(hipMemcpyAsync(sl.h_report, sl.d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost, c->d2h_stream));
     DCN_HIP(hipEventRecord(sl.done, c->d2h_stream));
     return DCN_OK;

@@ -105,6 +105,24 @@ def test_small_staging_ring_many_pieces_per_chunk(oracle, dcn, genome, index_pai
     proc.close()
 
 
+def test_empty_batches_between_real_ones(oracle, dcn, genome, index_pair):
+    """a batch without reads has no chunk: its report must still be this batch's (all zero), not the previous one's"""
+    oidx, gidx = index_pair
+    reads = sample_reads(np.random.default_rng(160), genome, 800, 50, 200)
+    b, o = oracle.concat_reads(reads)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=1 << 20, max_batch_reads=1 << 12)
+    want = oracle_batch(oracle, oidx, proc, b, o, None)
+    empty_b, empty_o = np.zeros(0, np.uint8), np.zeros(1, np.uint64)
+    for _ in range(3):
+        assert_same(proc.filter_batch(b, o), want)
+        for _ in range(4):
+            k = proc.submit(empty_b, empty_o, counts=False).wait()
+            assert len(k) == 0
+    s = proc.stats()
+    assert s["total_seqs"] == 3 * len(reads) and s["total_bp"] == 3 * len(b)
+    proc.close()
+
+
 def test_submit_wait_two_in_flight(oracle, dcn, genome, index_pair, monkeypatch):
     small_chunks(monkeypatch, 50_000)
     oidx, gidx = index_pair

@@ -1336,7 +1336,8 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     // With another batch already in flight the kernels of this batch's last chunk are covered by the next batch's
     // copies, so nothing argues for small chunks any more, and every chunk costs the host ~0.2 ms of runtime calls:
     // twice the chunk size then (packed input, two in flight: 105 -> 120 Gbp/s when the host was the limit).
-    const uint64_t chunk_bases = c->chunk_bases * (slots_busy(c) ? 2 : 1);
+    static const uint64_t inflight_factor = getenv("DCN_INFLIGHT_CHUNK_FACTOR") ? strtoull(getenv("DCN_INFLIGHT_CHUNK_FACTOR"), nullptr, 10) : 2;
+    const uint64_t chunk_bases = c->chunk_bases * (slots_busy(c) ? std::max<uint64_t>(inflight_factor, 1) : 1);
     for (int attempt = 0;; ++attempt) {
         sl.device_pack = tr == Transport::AsciiDirect || tr == Transport::AsciiStaged;
         sl.chunks.clear();

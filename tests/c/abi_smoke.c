@@ -1,0 +1,37 @@
+/* A plain C99 caller of the boundary: links libdeacon_hip.so, needs no GPU for what it calls.
+ * (tests/test_abi.py::test_c_caller_links_and_runs builds and runs it.)  Exit code 0 = every check held. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "deacon_hip.h"
+
+int main(void) {
+    const char *v = dcn_version();
+    if (!v || strncmp(v, "deacon-hip ", 11) != 0) return 1;
+
+    /* dcn_pack_ascii: PackedSeqVec::from_ascii's code (c >> 1) & 3 and the invalid-base mask, 32-base groups */
+    const char *seq = "ACGTacgtNNRYACGTACGTACGTACGTACGTACGTA"; /* 37 bases: two groups */
+    const uint64_t n = (uint64_t)strlen(seq);
+    uint32_t packed[4] = {0, 0, 0, 0}, mask[2] = {0, 0};
+    if (dcn_pack_ascii((const uint8_t *)seq, n, packed, mask) != DCN_OK) return 2;
+    for (uint64_t i = 0; i < n; ++i) {
+        unsigned code = (packed[i / 16] >> (2 * (i % 16))) & 3u;
+        unsigned bad = (mask[i / 32] >> (i % 32)) & 1u;
+        char c = seq[i], u = (char)(c & ~0x20);
+        if (code != (((unsigned)c >> 1) & 3u)) return 3;
+        if (bad != !(u == 'A' || u == 'C' || u == 'G' || u == 'T')) return 4;
+    }
+    /* argument errors are reported, never aborted on; the message is thread-local text */
+    if (dcn_pack_ascii(NULL, 5, packed, mask) != DCN_ERR_ARG || strlen(dcn_last_error()) == 0) return 5;
+    dcn_index *idx = NULL;
+    int rc = dcn_index_from_keys(NULL, 3, 31, 15, 0, &idx); /* keys == NULL with n > 0 */
+    if (rc != DCN_ERR_ARG || idx != NULL) return 6;
+    rc = dcn_index_from_file("/nonexistent/file.idx", 0, &idx);
+    if (rc == DCN_OK || idx != NULL) return 7;
+    int ndev = -1;
+    rc = dcn_device_count(&ndev); /* DCN_OK with a GPU, DCN_ERR_HIP without: either way no abort and a defined count */
+    if (ndev < 0) return 8;
+    printf("%s devices=%d rc=%d\n", v, ndev, rc);
+    return 0;
+}

@@ -99,3 +99,18 @@ def test_product_does_not_reference_the_oracle(dcn):
                 assert "liboracle" not in text and "deacon_oracle" not in text and "from oracle" not in text, f
     out = subprocess.check_output(["ldd", dcn._native.LIB_PATH], text=True)
     assert "oracle" not in out
+
+
+def test_c_caller_links_and_runs(tmp_path, dcn):
+    """the boundary is a C ABI: a C99 translation unit (tests/c/abi_smoke.c) includes the header, links the library and
+    calls the entry points that need no GPU (version, the host-side packer, argument errors)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(dcn._native.LIB_PATH)
+    exe = tmp_path / "abi_smoke"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", str(exe), "-L", libdir, "-ldeacon_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+    p = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
+    assert p.stdout.startswith("deacon-hip ")

@@ -28,6 +28,7 @@
 #include <cerrno>
 #include <chrono>
 #include <condition_variable>
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -872,6 +873,20 @@ class MappedOutput {
         data_ = (char *)p;
         reserve_ = reserve;
         g_sparse_out_fd = fd_;
+        // a full disk shows up as SIGBUS on a store into the mapping, not as an error code: report it like any other
+        // write error instead of dying silently
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = [](int) {
+            static const char msg[] = "Error: write error (output file could not grow)\n";
+            ssize_t ignored = ::write(2, msg, sizeof msg - 1);
+            (void)ignored;
+            int fd = g_sparse_out_fd.exchange(-1);
+            if (fd >= 0 && ftruncate(fd, 0) != 0) {
+            }
+            _exit(1);
+        };
+        sigaction(SIGBUS, &sa, nullptr);
         return true;
     }
     char *at(uint64_t off, uint64_t len) {

@@ -1538,6 +1538,38 @@ int main(int argc, char **argv) {
             if (pos.size() > 3) die("unexpected argument '" + pos[3] + "'");
             return run_filter(a);
         }
+        if (args[0] == "bench-parse" && args.size() >= 2) {  // hidden: the parser pool alone on a plain FASTX file (no GPU)
+            size_t threads = 8;
+            for (size_t i = 2; i + 1 < args.size(); ++i)
+                if (args[i] == "-t") threads = (size_t)std::atoll(args[i + 1].c_str());
+            MappedFile mf;
+            if (!mf.open(args[1])) die("cannot map " + args[1]);
+            const bool fq = mf.data[0] == '@';
+            auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::pair<size_t, size_t>> chunks;
+            const size_t chunk = std::min<size_t>(std::max<size_t>(mf.size / (4 * threads), 4u << 20), 24u << 20);
+            for (size_t pos = 0; pos < mf.size;) {
+                size_t end = pos + chunk >= mf.size ? mf.size : next_record_start(mf.data, mf.size, pos + chunk, fq);
+                chunks.emplace_back(pos, end);
+                pos = end;
+            }
+            std::atomic<size_t> next{0}, recs{0}, bases{0};
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < threads; ++t)
+                pool.emplace_back([&] {
+                    for (size_t i; (i = next.fetch_add(1)) < chunks.size();) {
+                        Batch b;
+                        parse_mapped_chunk(mf.data, chunks[i].first, chunks[i].second, fq, b);
+                        recs += b.recs.size();
+                        bases += b.bases.size();
+                    }
+                });
+            for (auto &t : pool) t.join();
+            double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("parsed %zu records, %zu bases, %.2f GB in %.3f s with %zu threads: %.2f GB/s, %.2f Gbp/s\n", recs.load(),
+                        bases.load(), mf.size / 1e9, s, threads, mf.size / s / 1e9, bases.load() / s / 1e9);
+            return 0;
+        }
         if (args[0] == "index" && args.size() >= 2 && args[1] == "build") {
             std::string input, output = "-";
             unsigned k = deacon::DEFAULT_KMER_LENGTH, w = deacon::DEFAULT_WINDOW_SIZE;

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -702,7 +703,7 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
 
 // A few host threads that split one large job (a copy or a pack) into slices: a single core moves ~10 GB/s into
 // the pinned staging buffer, which is less than the PCIe link takes out of it.  Process-wide, created on first
-// use; DCN_HOST_THREADS sets the width (default: up to 8, 1 = run inline).
+// use; DCN_HOST_THREADS sets the width (default: the usable CPUs, at most 12; 1 = run inline).
 class HostPool {
   public:
     static HostPool &get() {
@@ -746,8 +747,18 @@ class HostPool {
 
   private:
     HostPool() {
+        // CPUs this process may really use: the affinity mask, capped by the cgroup quota (a container often sees all of
+        // the host's hardware threads but is throttled to a share of them); at most 12 of those
         unsigned hw = std::thread::hardware_concurrency();
-        int want = (int)std::min<unsigned>(8, hw ? hw : 1);
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min<unsigned>(hw ? hw : 1024, (unsigned)CPU_COUNT(&set));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                hw = std::min<unsigned>(hw ? hw : 1024, (unsigned)std::max<long long>(1, quota / period));
+            fclose(f);
+        }
+        int want = (int)std::min<unsigned>(12, hw ? hw : 1);
         if (const char *e = getenv("DCN_HOST_THREADS")) want = atoi(e);
         n_threads_ = std::max(1, std::min(want, 64));
         for (int i = 1; i < n_threads_; ++i) workers_.emplace_back([this, i] { worker(i); });

@@ -263,7 +263,9 @@ enum {
     DCN_N_STAGES = 5
 };
 
-/* enable != 0: record events around every stage of every following batch (and clear the accumulators). */
+/* enable 1: record events around every stage of every following batch (and clear the accumulators); 2: around the
+ * scan stage only (two marker packets per batch instead of six: the form a throughput measurement can afford);
+ * 0: off. */
 int dcn_ctx_set_profiling(dcn_ctx *ctx, int enable);
 
 /* Accumulated device time per stage in milliseconds and the number of batches measured, for batches that

@@ -373,31 +373,56 @@ __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
 // ---- A7/A10: decision for units not resolved by the scan kernel + the six counters ----------------------------
 __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
     unsigned long long st[DCN_N_STATS] = {0, 0, 0, 0, 0, 0};
-    // grid-stride: few blocks, so the six counters see a few thousand atomics instead of one set per 256 units
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < a.n_units; u += gridDim.x * blockDim.x) {
-        uint32_t r0 = a.unit_first_read ? a.unit_first_read[u] : u;
-        uint32_t r1 = a.unit_first_read ? a.unit_first_read[u + 1] : u + 1;
-        bool keep;
-        if (a.unit_state[u]) {
-            keep = a.keep[u] != 0;
-        } else {
-            uint32_t tot = a.g_total[u], hc = a.g_distinct[u] + (a.g_zero[u] ? 1u : 0u);
-            keep = dcn_decide(hc, tot, a.abs_threshold, a.rel_threshold, a.deplete);
-            a.keep[u] = keep ? 1 : 0;
-            if (a.hits) a.hits[u] = hc;
-            if (a.total) a.total[u] = tot;
+    // grid-stride: few blocks, so the six counters see a few thousand atomics instead of one set per 256 units; four
+    // units per thread and step, their loads issued together (the loop is latency-bound: 0.036 -> 0.02 ms at 4 M units)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t u0 = blockIdx.x * blockDim.x + threadIdx.x; u0 < a.n_units; u0 += 4 * stride) {
+        uint8_t state[4], kept[4];
+        uint32_t r0[4], r1[4];
+        uint64_t o0[4], o1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t u = u0 + q * stride;
+            state[q] = 2; // 2 = no unit
+            if (u < a.n_units) {
+                state[q] = a.unit_state[u];
+                kept[q] = a.keep[u];
+                r0[q] = a.unit_first_read ? a.unit_first_read[u] : u;
+                r1[q] = a.unit_first_read ? a.unit_first_read[u + 1] : u + 1;
+            }
         }
-        if (a.offsets) {
-            // ProcessingStats, src/local_filter.rs:346-371 (single) / :417-445 (pair)
-            unsigned long long nseq = r1 - r0, bp = a.offsets[r1] - a.offsets[r0];
-            st[DCN_STAT_TOTAL_SEQS] += nseq;
-            st[DCN_STAT_TOTAL_BP] += bp;
-            if (keep) {
-                st[DCN_STAT_OUTPUT_BP] += bp;
-                st[DCN_STAT_OUTPUT_SEQ_COUNTER] += nseq;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (state[q] != 2 && a.offsets) {
+                o0[q] = a.offsets[r0[q]];
+                o1[q] = a.offsets[r1[q]];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (state[q] == 2) continue;
+            const uint32_t u = u0 + q * stride;
+            bool keep;
+            if (state[q]) {
+                keep = kept[q] != 0;
             } else {
-                st[DCN_STAT_FILTERED_SEQS] += nseq;
-                st[DCN_STAT_FILTERED_BP] += bp;
+                uint32_t tot = a.g_total[u], hc = a.g_distinct[u] + (a.g_zero[u] ? 1u : 0u);
+                keep = dcn_decide(hc, tot, a.abs_threshold, a.rel_threshold, a.deplete);
+                a.keep[u] = keep ? 1 : 0;
+                if (a.hits) a.hits[u] = hc;
+                if (a.total) a.total[u] = tot;
+            }
+            if (a.offsets) {
+                // ProcessingStats, src/local_filter.rs:346-371 (single) / :417-445 (pair)
+                unsigned long long nseq = r1[q] - r0[q], bp = o1[q] - o0[q];
+                st[DCN_STAT_TOTAL_SEQS] += nseq;
+                st[DCN_STAT_TOTAL_BP] += bp;
+                if (keep) {
+                    st[DCN_STAT_OUTPUT_BP] += bp;
+                    st[DCN_STAT_OUTPUT_SEQ_COUNTER] += nseq;
+                } else {
+                    st[DCN_STAT_FILTERED_SEQS] += nseq;
+                    st[DCN_STAT_FILTERED_BP] += bp;
+                }
             }
         }
     }

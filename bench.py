@@ -628,7 +628,8 @@ def main():
                       "level (no Rust toolchain, the reference holds no value vectors: DESIGN.md section 2)",
             "config": {
                 "workload": names[args.workload],
-                "index_keys": int(index.n_keys), "reads_per_batch_per_gpu": batches[0].n_reads,
+                "index_keys": int(index.n_keys), "index_table_bytes": int(index.table_bytes),
+                "reads_per_batch_per_gpu": batches[0].n_reads,
                 "bases_per_batch_per_gpu": batches[0].n_bases, "distinct_batches_rotated": len(batches),
                 "k": K, "w": W, "host_fraction": 0.5, "host_genome_bases": args.host_genome,
                 "parallelism": f"reads sharded x{world}, index replicated",

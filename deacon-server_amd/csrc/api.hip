@@ -236,6 +236,12 @@ extern "C" int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, 
     return DCN_OK;
 }
 
+extern "C" int dcn_index_memory(const dcn_index *index, uint64_t *table_bytes) {
+    if (!index || !table_bytes) return dcn_fail(DCN_ERR_ARG, "index/table_bytes is NULL");
+    *table_bytes = index->n_groups * DCN_GROUP_SLOTS * sizeof(uint64_t);
+    return DCN_OK;
+}
+
 extern "C" int dcn_index_device(const dcn_index *index, int *device) {
     if (!index || !device) return dcn_fail(DCN_ERR_ARG, "index/device is NULL");
     *device = index->device;

@@ -33,7 +33,13 @@ int dcn_fail(int code, const std::string &msg);
 #ifndef DCN_GROUP_SLOTS
 #define DCN_GROUP_SLOTS 2
 #endif
+// table size = the smallest power-of-two number of groups with >= S slots per key.  S is at least
+// DCN_SLOTS_PER_KEY; dcn_table_groups_for (index_table.hip) doubles it while the table stays small against the
+// device's 288 GB (every probe that finds its home group full is one more scattered request, and the scan
+// kernel's time follows the request count: 1.39 -> 1.35 ms on the headline batch for 17 -> 34 GB of table).
 constexpr int DCN_SLOTS_PER_KEY = DCN_GROUP_SLOTS == 2 ? 4 : 2;
+constexpr int DCN_SLOTS_PER_KEY_ROOMY = 2 * DCN_SLOTS_PER_KEY;
+constexpr uint64_t DCN_ROOMY_MAX_GROUPS = 1ull << 31; // 34 GB of 16-byte groups
 
 struct dcn_table_view {
     const uint64_t *slots; // n_groups * DCN_GROUP_SLOTS
@@ -164,6 +170,7 @@ int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint
                               hipStream_t stream);
 int dcn_table_insert_varint9(dcn_index *idx, const uint64_t *d_raw, uint64_t n, unsigned long long *d_new,
                              uint32_t *d_zero, uint32_t *d_bad, hipStream_t stream); // 9-byte varint records
+uint64_t dcn_table_groups_for(uint64_t n_keys);                                  // sizing rule (see DCN_SLOTS_PER_KEY)
 int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity);                 // empty table for >= that many keys
 int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity);               // grow + rehash if needed
 int dcn_table_insert_dump(dcn_index *idx, const uint64_t *d_hash, const uint8_t *d_valid, const uint32_t *d_abs_pos,

@@ -15,7 +15,14 @@ struct dcn_group {
 __device__ inline dcn_group dcn_load_group(const dcn_table_view &t, uint32_t g) {
     const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(t.slots + (uint64_t)g * DCN_GROUP_SLOTS);
     dcn_group r;
+#ifdef DCN_NT_PROBE
+    typedef unsigned long long dcn_u64x2 __attribute__((ext_vector_type(2)));
+    dcn_u64x2 q = __builtin_nontemporal_load(reinterpret_cast<const dcn_u64x2 *>(p));
+    r.a.x = q.x;
+    r.a.y = q.y;
+#else
     r.a = p[0];
+#endif
 #if DCN_GROUP_SLOTS == 4
     r.b = p[1];
 #endif

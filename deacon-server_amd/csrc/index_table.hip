@@ -8,6 +8,7 @@
 #include "dcn_probe.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -105,9 +106,7 @@ __global__ void table_contains_kernel(dcn_table_view t, const uint64_t *keys, ui
 
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n) {
     DCN_HIP(hipSetDevice(idx->device));
-    // capacity: >= DCN_SLOTS_PER_KEY slots per key, power-of-two number of groups, at least 64 groups
-    uint64_t groups = 64;
-    while (groups * DCN_GROUP_SLOTS < n * DCN_SLOTS_PER_KEY + 8) groups <<= 1;
+    uint64_t groups = dcn_table_groups_for(n);
     if (groups > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
     idx->n_groups = groups;
     DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
@@ -293,17 +292,34 @@ __global__ void export_keys_kernel(const uint64_t *slots, uint64_t n_slots, uint
     }
 }
 
-uint64_t groups_for(uint64_t n_keys) {
-    uint64_t groups = 64;
-    while (groups * DCN_GROUP_SLOTS < n_keys * DCN_SLOTS_PER_KEY + 8) groups <<= 1;
-    return groups;
-}
-
 } // namespace
+
+// capacity rule: power-of-two number of groups, at least 64, >= S slots per key.  S = DCN_SLOTS_PER_KEY_ROOMY when
+// that table is at most DCN_ROOMY_MAX_GROUPS groups and a third of the device's free memory, DCN_SLOTS_PER_KEY
+// otherwise; DCN_TABLE_SLOTS_PER_KEY=<n> fixes S (>= 2).  Call with the index's device current.
+uint64_t dcn_table_groups_for(uint64_t n_keys) {
+    auto groups_at = [&](uint64_t s) {
+        uint64_t groups = 64;
+        while (groups * DCN_GROUP_SLOTS < n_keys * s + 8) groups <<= 1;
+        return groups;
+    };
+    if (const char *e = getenv("DCN_TABLE_SLOTS_PER_KEY")) {
+        long s = atol(e);
+        if (s >= 2 && s <= 64) return groups_at((uint64_t)s);
+    }
+    uint64_t roomy = groups_at(DCN_SLOTS_PER_KEY_ROOMY);
+    if (roomy <= DCN_ROOMY_MAX_GROUPS) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && roomy * DCN_GROUP_SLOTS * sizeof(uint64_t) <= free_b / 3)
+            return roomy;
+        (void)hipGetLastError();
+    }
+    return groups_at(DCN_SLOTS_PER_KEY);
+}
 
 int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity) {
     DCN_HIP(hipSetDevice(idx->device));
-    uint64_t groups = groups_for(n_keys_capacity);
+    uint64_t groups = dcn_table_groups_for(n_keys_capacity);
     if (groups > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
     idx->n_groups = groups;
     DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
@@ -319,7 +335,7 @@ int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity) {
 // make room for n_keys_capacity keys: allocate a larger table and re-insert every stored key
 int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity) {
     DCN_HIP(hipSetDevice(idx->device));
-    uint64_t want = groups_for(n_keys_capacity);
+    uint64_t want = dcn_table_groups_for(n_keys_capacity);
     if (want <= idx->n_groups) return DCN_OK;
     if (want > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
     uint64_t *old_slots = idx->d_slots;

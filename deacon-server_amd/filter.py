@@ -147,6 +147,13 @@ class Index:
         N.check(N.lib().dcn_index_clone(self._h, int(device), C.byref(h)))
         return type(self)(h, int(device))
 
+    @property
+    def table_bytes(self):
+        """device memory of the hash table (dcn_index_memory)"""
+        b = C.c_uint64()
+        N.check(N.lib().dcn_index_memory(self._h, C.byref(b)))
+        return b.value
+
     def diff(self, other):
         """index::diff (index.rs:421-536): the minimizers of self that are not in other."""
         h = C.c_void_p()

@@ -108,6 +108,11 @@ int dcn_index_header(const dcn_index *index, uint8_t *k, uint8_t *w, uint64_t *n
 /* The HIP device the index lives on. */
 int dcn_index_device(const dcn_index *index, int *device);
 
+/* Bytes of device memory the index's hash table occupies (a power-of-two number of 16-byte groups with at least
+ * four slots per key, eight while that stays within 34 GB and a third of the device's free memory:
+ * DESIGN.md section 3; the reference's FxHashSet<u64> is ~9-18 bytes per key of host memory). */
+int dcn_index_memory(const dcn_index *index, uint64_t *table_bytes);
+
 /* Set membership for `n` host keys -> out[i] in {0,1}: FxHashSet::contains (src/filter_common.rs:144). */
 int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n, uint8_t *out);
 

@@ -118,6 +118,11 @@ class Index {
         check(dcn_index_device(h_, &d));
         return d;
     }
+    uint64_t table_bytes() const {
+        uint64_t b = 0;
+        check(dcn_index_memory(h_, &b));
+        return b;
+    }
     const dcn_index *raw() const { return h_; }
 
   private:

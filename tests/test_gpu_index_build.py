@@ -121,3 +121,30 @@ def test_union_and_diff_set_algebra(oracle, dcn):
         dcn.Index.union([ia, other])
     with pytest.raises(dcn.DeaconHipError):
         ia.diff(other)
+
+
+def test_table_sizing_rule_changes_memory_not_results(dcn, monkeypatch):
+    """the table is a power-of-two number of 16-byte groups with >= S slots per key (S = 8 while the table stays
+    small against the device, 4 otherwise, DCN_TABLE_SLOTS_PER_KEY fixes it): dcn_index_memory reports the size;
+    membership, the key export and a clone do not depend on it, also at a load where most probes walk"""
+    rng = np.random.default_rng(77)
+    keys = np.unique(np.concatenate([rng.integers(0, 2**64, 300_000, dtype=np.uint64), np.zeros(1, np.uint64)]))
+    absent = np.setdiff1d(rng.integers(0, 2**64, 100_000, dtype=np.uint64), keys)
+    sizes = {}
+    for s in (None, 2, 4, 8, 16):
+        if s is None:
+            monkeypatch.delenv("DCN_TABLE_SLOTS_PER_KEY", raising=False)
+        else:
+            monkeypatch.setenv("DCN_TABLE_SLOTS_PER_KEY", str(s))
+        idx = dcn.Index.from_keys(keys, 31, 15)
+        sizes[s] = idx.table_bytes
+        assert idx.n_keys == len(keys)
+        assert idx.contains(keys).all() and not idx.contains(absent).any()
+        assert np.array_equal(np.sort(idx.keys()), keys)
+        rep = idx.clone(0)
+        assert rep.table_bytes == idx.table_bytes and rep.contains(keys[::7]).all()
+        rep.close()
+        idx.close()
+    groups = lambda s: max(64, 1 << int(np.ceil(np.log2((len(keys) * s + 8) / 2))))  # noqa: E731
+    assert sizes[None] == sizes[8] == 16 * groups(8)
+    assert [sizes[s] for s in (2, 4, 16)] == [16 * groups(s) for s in (2, 4, 16)]

@@ -354,6 +354,25 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
     return res, counters, elapsed, bases_done
 
 
+def probe_only_rate(index, device, n=64_000_000, reps=5):
+    """The library's own set-membership kernel (dcn_index_contains_device: one 16-byte group read per key, nothing else)
+    on n uniformly random keys against the SAME table: the scattered-request rate this box gives this table now.
+    Reported beside the documented ceiling (profiles/microbench/probe_patterns.hip), which moves 46 -> 49 G/s from
+    box to box."""
+    q = torch.randint(-2**63, 2**63 - 1, (n,), dtype=torch.int64, device=device)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(2):
+        index.contains_device(q.data_ptr(), n, out.data_ptr())
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(reps):
+        index.contains_device(q.data_ptr(), n, out.data_ptr())
+    ev[1].record()
+    torch.cuda.synchronize()
+    return n * reps / (ev[0].elapsed_time(ev[1]) * 1e-3)
+
+
 # ---- oracle checks (the checker, never the thing measured) -----------------------------------------------------------
 def sample_of(batch, max_bases):
     """first reads of a batch (whole units), at most max_bases bases -> host arrays"""
@@ -612,6 +631,8 @@ def main():
                 pass
         rf = head["roofline"]
         rf["traffic"] = traffic
+        rf["probe_only_kernel_live_per_s"] = probe_only_rate(index, device)
+        rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
         if traffic:
             # measured HBM traffic (PMC) over the live launch time: what the probe kernel really pulls from HBM
             rf["traffic_rate_GBps"] = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9

@@ -339,7 +339,7 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": algo, "avg_launch_ms": scan_ms, "minimizers_per_launch": int(mins),
             # second ceiling, reported beside the contract's: every minimizer is one scattered 16-byte request, and the
-            # chip serves ~46 G of those per second from a 17 GB table however they are issued (profiles/r01_probe_patterns_*)
+            # chip serves ~46 G of those per second from a 17-34 GB table however they are issued (profiles/r01_probe_patterns_*)
             "scattered_probes_per_s": mins / (scan_ms * 1e-3), "scattered_ceiling_per_s": SCATTER_CEILING,
             "frac_of_scattered_ceiling": mins / (scan_ms * 1e-3) / SCATTER_CEILING,
         },

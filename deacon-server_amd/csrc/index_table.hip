@@ -97,10 +97,43 @@ __global__ void table_insert_varint9_kernel(uint64_t *slots, uint32_t group_shif
     if (fresh) atomicAdd(n_new, fresh);
 }
 
+// four keys per thread and step, their home groups in flight together (one dwordx4 each); the rare key whose home
+// group is full without it walks on afterwards
 __global__ void table_contains_kernel(dcn_table_view t, const uint64_t *keys, uint64_t n, uint8_t *out) {
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        out[i] = dcn_table_contains_dev(t, keys[i]) ? 1 : 0;
+    constexpr int U = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+        uint64_t key[U];
+        uint32_t grp[U];
+        dcn_group g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + u * stride;
+            key[u] = i < n ? keys[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            grp[u] = dcn_group_of(key[u], t.group_shift, t.group_mask);
+            g[u] = dcn_load_group(t, grp[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + u * stride;
+            if (i >= n) continue;
+            bool hit;
+            if (key[u] == 0) {
+                hit = t.has_zero != 0;
+            } else {
+                int r = dcn_group_resolve(g[u], key[u]);
+                while (r < 0) {
+                    grp[u] = (grp[u] + 1) & t.group_mask;
+                    r = dcn_group_resolve(dcn_load_group(t, grp[u]), key[u]);
+                }
+                hit = r == 1;
+            }
+            out[i] = hit ? 1 : 0;
+        }
+    }
 }
 } // namespace
 

@@ -22,6 +22,9 @@
 #include <sys/uio.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -329,6 +332,24 @@ struct Rec {
     uint32_t rec_len = 0;
 };
 
+// std::allocator value-initialises on resize(): a 12 MB zero fill per parsed chunk that the parser overwrites at once
+template <typename T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <typename U>
+    void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void *>(p)) U;
+    }
+    template <typename U, typename... Args>
+    void construct(U *p, Args &&...args) {
+        ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...);
+    }
+};
+
 struct Batch {
     uint64_t seq_no = 0;
     std::vector<char> text;      // ids and qualities (streaming reader) ...
@@ -337,7 +358,7 @@ struct Batch {
     std::vector<char> out1, out2;  // formatted kept records (filled by the format stage)
     std::vector<struct iovec> iov1;  // plain single-file output: what to write, in order -- ranges of the mapped input
                                      // (records that already have their output form) and pieces of out1
-    std::vector<uint8_t> bases;  // concatenated sequences (what dcn_filter_batch takes)
+    std::vector<uint8_t, DefaultInitAllocator<uint8_t>> bases;  // concatenated sequences (what dcn_filter_batch takes)
     std::vector<uint64_t> offsets{0};
     std::vector<uint32_t> unit_id;
     std::vector<Rec> recs;
@@ -357,6 +378,49 @@ struct Batch {
         unit_id.clear();
         recs.clear();
     }
+    void reset() {  // back to a fresh batch that keeps its vectors' memory
+        clear();
+        seq_no = 0;
+        ext = nullptr;
+        out1.clear();
+        out2.clear();
+        iov1.clear();
+        keep.clear();
+        hits.clear();
+        total.clear();
+        gpu_seqs.clear();
+        sub_off.clear();
+        sub_uid.clear();
+        out_off = out_bytes = 0;
+        paired = false;
+    }
+};
+
+// Batches travel reader -> parsers -> GPU stage -> formatters -> writer and come back here: their vectors (12 MB of
+// bases, 5 MB of records per chunk) are reused instead of being mapped, page-faulted and unmapped once per chunk
+class BatchPool {
+  public:
+    std::unique_ptr<Batch> get() {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            if (!free_.empty()) {
+                std::unique_ptr<Batch> b = std::move(free_.back());
+                free_.pop_back();
+                return b;
+            }
+        }
+        return std::unique_ptr<Batch>(new Batch());
+    }
+    void put(std::unique_ptr<Batch> b) {
+        if (!b) return;
+        b->reset();
+        std::lock_guard<std::mutex> l(m_);
+        free_.push_back(std::move(b));
+    }
+
+  private:
+    std::mutex m_;
+    std::vector<std::unique_ptr<Batch>> free_;
 };
 
 // streaming parser over a refillable window; one record at a time, appended to a Batch
@@ -597,17 +661,41 @@ size_t next_record_start(const char *d, size_t size, size_t from, bool fastq) {
     return size;
 }
 
+// index of the first '\n' in [p, size), or size.  Lines of a short-read file are 10-300 bytes: a libc call per line
+// costs more than the search, so the first 128 bytes are looked at here, 32 at a time
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline size_t line_end_avx2(const char *d, size_t size, size_t p) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t q = p;
+    for (int i = 0; i < 4 && q + 32 <= size; ++i, q += 32) {
+        const unsigned m = (unsigned)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(d + q)), nl));
+        if (m) return q + (size_t)__builtin_ctz(m);
+    }
+    return line_end(d, size, q);
+}
+#endif
+
 // parse the records in [a, b) of the mapped file into batch (ids / qualities stay in the mapping)
-void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
+template <bool AVX2>
+void parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
     out.ext = d;
-    // one allocation each instead of the doubling growth of push_back / insert (which copied every base ~twice)
-    out.bases.reserve((b - a) / (fastq ? 2 : 1) + 64);
+    auto eol = [&](size_t p) {
+#if defined(__x86_64__)
+        if (AVX2) return line_end_avx2(d, b, p);
+#endif
+        return line_end(d, b, p);
+    };
+    // the sequences of a chunk are at most its own size: one allocation, written through a raw pointer (insert() /
+    // push_back() per record cost more than the copy itself)
+    out.bases.resize((b - a) / (fastq ? 2 : 1) + 64);
+    uint8_t *bases = out.bases.data();
+    size_t nb = 0;
     out.recs.reserve((b - a) / 192 + 16);
     out.offsets.reserve((b - a) / 192 + 17);
     size_t p = a;
     auto trim = [&](size_t s0, size_t e) { return (e > s0 && d[e - 1] == '\r') ? e - 1 : e; };
     while (p < b) {
-        size_t e0 = line_end(d, b, p);
+        size_t e0 = eol(p);
         if (e0 == p) {  // blank line
             p = e0 + 1;
             continue;
@@ -616,18 +704,17 @@ void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &ou
         Rec r;
         r.id_off = p + 1;
         r.id_len = (uint32_t)(trim(p + 1, e0) - (p + 1));
-        r.seq_off = out.bases.size();
+        r.seq_off = nb;
         if (fastq) {
-            // two of the four line ends are where the first two put them in a well-formed record ("+\n", then a
-            // quality line as long as the sequence line): look there before searching
-            size_t s1 = e0 + 1, e1 = line_end(d, b, s1), s2 = e1 + 1;
-            size_t e2 = (s2 + 1 < b && d[s2 + 1] == '\n') ? s2 + 1 : line_end(d, b, s2);
-            size_t s3 = e2 + 1, e3 = s3 + (e1 - s1);
-            if (e3 > b || (e3 < b && d[e3] != '\n') || std::memchr(d + s3, '\n', e3 - s3)) e3 = line_end(d, b, s3);
+            // (the '+' line of a well-formed record is "+\n": look there before searching)
+            size_t s1 = e0 + 1, e1 = eol(s1), s2 = e1 + 1;
+            size_t e2 = (s2 + 1 < b && d[s2 + 1] == '\n') ? s2 + 1 : eol(s2);
+            size_t s3 = e2 + 1, e3 = eol(s3);
             if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
             size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
-            out.bases.insert(out.bases.end(), d + s1, d + t1);
             if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
+            std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
+            nb += t1 - s1;
             r.qual_off = s3;
             if (t1 == e1 && t3 == e3 && e2 == s2 + 1 && e3 < b && r.id_len == e0 - (p + 1) && e3 + 1 - p < (1ull << 32)) {
                 r.rec_off = p;
@@ -638,9 +725,10 @@ void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &ou
             size_t q = e0 + 1, lines = 0, last_e = 0;
             bool cr = false;
             while (q < b && d[q] != '>') {
-                size_t e = line_end(d, b, q);
+                size_t e = eol(q);
                 cr = cr || trim(q, e) != e;
-                out.bases.insert(out.bases.end(), d + q, d + trim(q, e));
+                std::memcpy(bases + nb, d + q, trim(q, e) - q);
+                nb += trim(q, e) - q;
                 q = e + 1;
                 last_e = e;
                 ++lines;
@@ -652,10 +740,19 @@ void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &ou
             }
             p = q;
         }
-        r.seq_len = (uint32_t)(out.bases.size() - r.seq_off);
+        r.seq_len = (uint32_t)(nb - r.seq_off);
         out.recs.push_back(r);
-        out.offsets.push_back(out.bases.size());
+        out.offsets.push_back(nb);
     }
+    out.bases.resize(nb);
+}
+
+void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !std::getenv("DCN_CLI_NO_AVX2");
+    if (avx2) return parse_mapped_chunk_impl<true>(d, a, b, fastq, out);
+#endif
+    parse_mapped_chunk_impl<false>(d, a, b, fastq, out);
 }
 
 struct BatchStats {
@@ -1068,6 +1165,7 @@ int run_filter(const FilterArgs &a) {
     struct Chunk {
         size_t a, b;
     };
+    BatchPool pool;
     Queue<std::unique_ptr<Batch>> parsed(4);
     std::unique_ptr<OrderedStage> parse_stage;
     std::thread reader;
@@ -1091,7 +1189,7 @@ int run_filter(const FilterArgs &a) {
             size_t pos = 0;
             while (pos < size) {
                 size_t end = pos + chunk >= size ? size : next_record_start(d, size, pos + chunk, fastq_in);
-                std::unique_ptr<Batch> b(new Batch());
+                std::unique_ptr<Batch> b = pool.get();
                 b->offsets[0] = pos;  // see the worker lambda
                 b->seq_no = end;
                 parse_stage->push(std::move(b));
@@ -1106,7 +1204,7 @@ int run_filter(const FilterArgs &a) {
             if (paired && !paired_stdin) r2.reset(new FastxReader(a.input2));
             bool more = true;
             while (more) {
-                std::unique_ptr<Batch> b(new Batch());
+                std::unique_ptr<Batch> b = pool.get();
                 b->paired = paired;
                 while (b->bases.size() < batch_bases && b->recs.size() < batch_reads) {
                     if (!r1.next(*b)) {
@@ -1167,14 +1265,16 @@ int run_filter(const FilterArgs &a) {
     std::thread writer([&] {
         std::unique_ptr<Batch> b;
         while (format_stage.pop(b)) {
-            if (map_out) continue;  // already in place
-            StageClock::Scope sc(t_write);
-            if (gather_out) {
-                out1_holder->write_gather(b->iov1);
-                continue;
+            if (!map_out) {  // (mapped output: already in place)
+                StageClock::Scope sc(t_write);
+                if (gather_out) {
+                    out1_holder->write_gather(b->iov1);
+                } else {
+                    out1_holder->write(b->out1);
+                    if (out2) out2->write(b->out2);
+                }
             }
-            out1_holder->write(b->out1);
-            if (out2) out2->write(b->out2);
+            pool.put(std::move(b));
         }
     });
 
@@ -1557,8 +1657,9 @@ int main(int argc, char **argv) {
             std::vector<std::thread> pool;
             for (size_t t = 0; t < threads; ++t)
                 pool.emplace_back([&] {
+                    Batch b;  // recycled, as the pipeline's pool does
                     for (size_t i; (i = next.fetch_add(1)) < chunks.size();) {
-                        Batch b;
+                        b.clear();
                         parse_mapped_chunk(mf.data, chunks[i].first, chunks[i].second, fq, b);
                         recs += b.recs.size();
                         bases += b.bases.size();

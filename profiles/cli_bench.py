@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """f2 measurement: `deacon-hip filter` end to end on files (tmpfs): FASTQ parse -> GPU -> FASTQ write.
-usage: python profiles/cli_bench.py [n_reads] [genome_bases] [index_keys]
+usage: python profiles/cli_bench.py [n_reads] [genome_bases] [index_keys] [host_fraction]
+  host_fraction (default 0.5): share of the reads drawn from the indexed genome; a host-depletion run of a clinical
+  sample is 0.9-0.99 (`-d` then writes the few per cent that are left), a 0.5 mix writes half of the input back
   index_keys > 0: the index file also holds mix64 keys up to that many (409913780 = panhuman-1's size, a 3.7 GB file)
 Variants run on the same files: DCN_CLI_VARIANTS = ';'-separated entries of space-separated tokens, each token
 either ENV=VALUE or a command-line argument, e.g. "-t 16;DCN_CLI_NO_MMAP_OUT=1 -t 16" (default: one run, no extras).
@@ -21,6 +23,7 @@ BIN = os.path.join(ROOT, "deacon-server_amd", "bin", "deacon-hip")
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 n_genome = int(sys.argv[2]) if len(sys.argv) > 2 else 64_000_000
 n_keys = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+host_frac = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5
 rng = np.random.default_rng(1)
 d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 try:
@@ -56,12 +59,12 @@ try:
         big.close()
         del keys
         print(f"panhuman-sized index: {n_keys:,} keys -> {os.path.getsize(idx_path)/1e9:.2f} GB file in {time.perf_counter()-t:.1f} s", flush=True)
-    # FASTQ with 150 bp reads, half from the genome
+    # FASTQ with 150 bp reads, host_frac of them from the genome
     L = 150
     starts = rng.integers(0, n_genome - L, n_reads)
     mat = genome[starts[:, None] + np.arange(L)[None, :]]
     rnd = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n_reads, L))]
-    host = rng.random(n_reads) < 0.5
+    host = rng.random(n_reads) < host_frac
     mat = np.where(host[:, None], mat, rnd)
     rec = np.empty((n_reads, 2 * L + 16), np.uint8)
     ids = np.char.zfill(np.arange(n_reads).astype(str), 9).astype("S9")
@@ -80,7 +83,17 @@ try:
     del rec, mat, rnd
     size = os.path.getsize(fq)
     variants = [v.split() for v in os.environ.get("DCN_CLI_VARIANTS", "").split(";")] or [[]]
-    modes = (("search", []), ("deplete", ["-d"])) if not os.environ.get("DCN_CLI_SEARCH_ONLY") else (("search", []),)
+    # a variant may name another driver binary (DCN_CLI_BIN=path, relative to the repo): old vs new on the same files
+    bins = sorted({t_.split("=", 1)[1] for v in variants for t_ in v if t_.startswith("DCN_CLI_BIN=")} | {BIN})
+    for b_ in bins:
+        for th in (8, 16):
+            p = subprocess.run([os.path.join(ROOT, b_), "bench-parse", fq, "-t", str(th)], capture_output=True, text=True)
+            print(f"[{os.path.basename(b_)}] {p.stdout.strip()}", flush=True)
+    modes = (("search", []), ("deplete", ["-d"]))
+    if os.environ.get("DCN_CLI_SEARCH_ONLY"):
+        modes = modes[:1]
+    if os.environ.get("DCN_CLI_DEPLETE_ONLY"):
+        modes = modes[1:]
     for vi, toks in enumerate(variants):
         envs = dict(t_.split("=", 1) for t_ in toks if re.match(r"^[A-Z_]+=", t_))
         args = [t_ for t_ in toks if not re.match(r"^[A-Z_]+=", t_)]
@@ -88,7 +101,7 @@ try:
             env = dict(os.environ, DCN_CLI_TIMING="1", **envs)
             out = os.path.join(d, "out.fq")
             t = time.perf_counter()
-            p = subprocess.run([BIN, "filter", idx_path, fq, "-o", out, "-s", os.path.join(d, "s.json"), "-q", *extra, *args],
+            p = subprocess.run([os.path.join(ROOT, envs.get("DCN_CLI_BIN", BIN)), "filter", idx_path, fq, "-o", out, "-s", os.path.join(d, "s.json"), "-q", *extra, *args],
                                check=True, env=env, capture_output=True, text=True)
             dt = time.perf_counter() - t
             s = json.load(open(os.path.join(d, "s.json")))

@@ -67,6 +67,8 @@ def test_differential(oracle, dcn, seed, monkeypatch):
     monkeypatch.setenv("DCN_STAGE_BYTES", str(int(rng.choice([4096, 65536, 32 << 20]))))
     if rng.random() < 0.3:
         monkeypatch.setenv("DCN_NO_HOST_PACK", "1")
+    # table load: 2 slots per key makes most probes of a present key walk past a full home group, 8 almost none
+    monkeypatch.setenv("DCN_TABLE_SLOTS_PER_KEY", str(int(np.random.default_rng(seed).choice([2, 4, 8]))))
     indexes = {}
     for case in range(10):
         k, w, reads, uid, params = random_case(rng, genome)

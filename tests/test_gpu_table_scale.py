@@ -107,3 +107,88 @@ def test_950m_key_table_membership_and_mixed_deplete_batch(oracle, dcn):
     gidx.close()
     print(f"950M-key table: keys {t_keys:.1f} s, table {t_table:.1f} s, whole test {time.time() - t0:.1f} s")
     assert time.time() - t0 < 90
+
+
+@pytest.mark.gpu
+def test_one_batch_beyond_2_to_the_32_bases(oracle, dcn):
+    """maximum sizes: ONE device-resident batch of 4.43 Gbp (base offsets, run slots and packed-stream bit positions
+    above 2^32), short reads first and 100 kbp host-derived reads at its far end (their hit runs sit in record slots
+    above 2^32).  The same reads in five pieces of < 2^30 bases through a small context must give the same keep /
+    hits / totals; the reads at the far end are also compared with the oracle."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4321)
+    genome = random_reads(rng, 1, 3_000_000, 3_000_000)[0]
+    oidx = oracle.Index.build([genome], k=31, w=15)
+    gidx = dcn.Index.from_keys(oidx.keys(), 31, 15)
+    g_dev = torch.from_numpy(np.frombuffer(genome, np.uint8).copy()).to(dev)
+    n_short, L, n_long, LL = 27_500_000, 150, 3_000, 100_000
+    n_reads = n_short + n_long
+    n_bases = n_short * L + n_long * LL
+    assert n_bases > (1 << 32) + (1 << 26)
+    d_bases = torch.empty(n_bases, dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    ar = torch.arange(L, device=dev, dtype=torch.int32)
+    step = 2_500_000
+    for a in range(0, n_short, step):  # half of the short reads from the genome, half random
+        m = min(step, n_short - a)
+        st = torch.randint(0, len(genome) - L, (m,), device=dev, generator=gen, dtype=torch.int32)
+        mat = g_dev[(st[:, None] + ar[None, :]).long()]
+        rnd = acgt[torch.randint(0, 4, (m, L), device=dev, generator=gen)]
+        host = torch.rand(m, device=dev, generator=gen) < 0.5
+        d_bases[a * L:(a + m) * L] = torch.where(host[:, None], mat, rnd).reshape(-1)
+        del st, mat, rnd, host
+    long_starts = rng.integers(0, len(genome) - LL, n_long)
+    for i, s0 in enumerate(long_starts):  # long reads: verbatim genome segments, every 17th with a few N
+        o = n_short * L + i * LL
+        d_bases[o:o + LL] = g_dev[s0:s0 + LL]
+        if i % 17 == 0:
+            d_bases[o + 5_000:o + 5_003] = ord("N")
+    offsets = np.concatenate([np.arange(n_short, dtype=np.uint64) * np.uint64(L),
+                              np.uint64(n_short * L) + np.arange(n_long + 1, dtype=np.uint64) * np.uint64(LL)])
+    assert int(offsets[-1]) == n_bases and len(offsets) == n_reads + 1
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    out = {k_: torch.zeros(n_reads, dtype=t_, device=dev) for k_, t_ in (("keep", torch.uint8), ("hits", torch.int32), ("total", torch.int32))}
+    big = dcn.FilterProcessor(gidx, max_batch_bases=n_bases, max_batch_reads=n_reads)
+    big.reserve_records(n_long * LL // 4)
+    for counts in (True, False):
+        big.filter_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, n_bases, out["keep"].data_ptr(),
+                                out["hits"].data_ptr() if counts else None, out["total"].data_ptr() if counts else None)
+        big.synchronize()
+        if counts:
+            keep_counting = out["keep"].clone()
+        else:
+            assert torch.equal(out["keep"], keep_counting)  # decisions-only mode on the same batch
+    big.close()
+    # the same reads in pieces
+    cuts = [0, 6_000_000, 13_000_000, 20_000_000, n_short, n_reads]
+    piece_bases = max(int(offsets[cuts[i + 1]] - offsets[cuts[i]]) for i in range(5))
+    assert piece_bases < (1 << 30) + (1 << 28)
+    small = dcn.FilterProcessor(gidx, max_batch_bases=piece_bases, max_batch_reads=max(cuts[i + 1] - cuts[i] for i in range(5)))
+    small.reserve_records(n_long * LL // 4)
+    ref = {k_: torch.zeros_like(v) for k_, v in out.items()}
+    for i in range(5):
+        r0, r1 = cuts[i], cuts[i + 1]
+        b0, b1 = int(offsets[r0]), int(offsets[r1])
+        off_i = torch.from_numpy((offsets[r0:r1 + 1] - offsets[r0]).view(np.int64)).to(dev)
+        small.filter_batch_device(d_bases[b0:b1].data_ptr(), off_i.data_ptr(), r1 - r0, b1 - b0, ref["keep"][r0:].data_ptr(),
+                                  ref["hits"][r0:].data_ptr(), ref["total"][r0:].data_ptr())
+        small.synchronize()
+    small.close()
+    for k_ in ("total", "hits", "keep"):
+        bad = torch.nonzero(out[k_] != ref[k_]).flatten()
+        assert bad.numel() == 0, (k_, bad[:5].tolist(), out[k_][bad[:5]].tolist(), ref[k_][bad[:5]].tolist())
+    # far end against the oracle: the last 3000 short reads and the last 40 long reads (all above base 2^32)
+    r0 = n_short - 3_000
+    assert int(offsets[r0]) > (1 << 32) - (1 << 29)
+    for ra, rb in ((r0, n_short), (n_reads - 40, n_reads)):
+        b0, b1 = int(offsets[ra]), int(offsets[rb])
+        assert rb != n_reads or b0 > (1 << 32)
+        hb = d_bases[b0:b1].cpu().numpy()
+        want = oracle.filter_batch(oidx, hb, offsets[ra:rb + 1] - offsets[ra], threads=8)
+        assert want[2].tolist() == out["total"][ra:rb].cpu().tolist()
+        assert want[1].tolist() == out["hits"][ra:rb].cpu().tolist()
+        assert want[0].tolist() == out["keep"][ra:rb].cpu().tolist()
+    assert int(out["hits"][n_short:].min()) > 1000  # the long reads really are host reads with long runs

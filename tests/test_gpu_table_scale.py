@@ -192,3 +192,39 @@ def test_one_batch_beyond_2_to_the_32_bases(oracle, dcn):
         assert want[1].tolist() == out["hits"][ra:rb].cpu().tolist()
         assert want[0].tolist() == out["keep"][ra:rb].cpu().tolist()
     assert int(out["hits"][n_short:].min()) > 1000  # the long reads really are host reads with long runs
+
+
+@pytest.mark.gpu
+def test_one_host_batch_beyond_2_to_the_32_bases(oracle, dcn):
+    """the host entry points on ONE call of 4.35 Gbp (pageable ASCII through the chunked pipeline, then the same
+    stream 2-bit packed): the batch is a block of 1 M reads repeated 29 times, so every repetition must give the
+    block's results, and the block's results are the oracle's."""
+    rng = np.random.default_rng(99)
+    genome = random_reads(rng, 1, 1_000_000, 1_000_000)[0]
+    oidx = oracle.Index.build([genome], k=31, w=15)
+    gidx = dcn.Index.from_keys(oidx.keys(), 31, 15)
+    nb, L, reps = 1_000_000, 150, 29
+    g = np.frombuffer(genome, np.uint8)
+    st = rng.integers(0, len(genome) - L, nb)
+    block = g[st[:, None] + np.arange(L)[None, :]].copy()
+    rnd = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (nb, L))]
+    host = rng.random(nb) < 0.5
+    block[~host] = rnd[~host]
+    block[rng.random(nb) < 0.01, 70] = ord("N")
+    block = block.reshape(-1)
+    bases = np.tile(block, reps)
+    n_reads = nb * reps
+    assert len(bases) > (1 << 32)
+    offsets = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(L)
+    want = oracle.filter_batch(oidx, block, offsets[:nb + 1], threads=8)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=len(bases), max_batch_reads=n_reads)
+    keep, hits, total = proc.filter_batch(bases, offsets)
+    for name, got, ref in (("total", total, want[2]), ("hits", hits, want[1]), ("keep", keep, want[0])):
+        got = got.reshape(reps, nb)
+        bad = np.nonzero((got != np.asarray(ref)[None, :]).any(axis=1))[0]
+        assert len(bad) == 0, (name, "repetitions that differ from the oracle's block:", bad[:5].tolist())
+    packed, mask = dcn.pack_ascii(bases)
+    del bases
+    kp = proc.filter_batch_packed(packed, mask, offsets, counts=False)
+    assert (np.asarray(kp).reshape(reps, nb) == np.asarray(want[0])[None, :]).all()
+    proc.close()

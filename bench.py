@@ -562,7 +562,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=21)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=4_000_000, help="reads per batch per GPU (150 bp each)")
+    ap.add_argument("--reads", type=int, default=10_000_000,
+                    help="reads per batch per GPU (150 bp each); the default is SURVEY.md 8d config 2 whole: 10 M x 150 bp = 1.5 Gbp per step")
     ap.add_argument("--index-keys", type=int, default=PANHUMAN_KEYS)
     ap.add_argument("--host-genome", type=int, default=64_000_000,
                     help="bases of the synthetic host genome (SURVEY.md 8d config 2: 64 Mbp, ~8 M of the index keys)")

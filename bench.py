@@ -16,7 +16,7 @@ Prints ONE JSON line on rank 0 (see the task contract): value = whole-job Mbp/s 
   roofline      dominant kernel (scan): algorithmic HBM bytes / HIP-event time on the kernel's own stream
   cpu_baseline  the CPU oracle (oracle/, "port") on a bounded sample of the same reads, all host cores
 and, at N = 1 (after the timed region; none of it enters `value`):
-  workloads.{long,paired,union950m,host1g}   BASELINE configs[2], [3], [4]-sized table, and a >= 1 Gbp host genome
+  workloads.{long,paired,union950m,host1g,host95}   BASELINE configs[2], [3], [4]-sized table, and a >= 1 Gbp host genome
   host_path.{pageable,pinned,packed,...}     the PCIe-inclusive rate of dcn_filter_batch* from host memory
 each with its own roofline block and a check of the GPU's decisions against the CPU oracle on a bounded sample.
 """
@@ -228,11 +228,11 @@ class Batch:
         self.d_keep2 = torch.zeros(self.n_units, dtype=torch.uint8, device=dev)
 
 
-def make_batches(kind, genome_dev, reads, seed, device, rotate=ROTATE):
+def make_batches(kind, genome_dev, reads, seed, device, rotate=ROTATE, host_frac=0.5):
     out = []
     for i in range(rotate):
         if kind == "short":
-            b = make_reads(genome_dev, reads, seed + 100 * i, device)
+            b = make_reads(genome_dev, reads, seed + 100 * i, device, host_frac=host_frac)
             out.append(Batch(b, torch.arange(reads + 1, dtype=torch.int64, device=device) * READ_LEN))
         elif kind == "paired":
             n = reads // 2 * 2
@@ -573,7 +573,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other configs and the host-path measurements that follow the headline at N = 1")
-    ap.add_argument("--extras", default="long,paired,host_path,host1g,union950m",
+    ap.add_argument("--extras", default="long,paired,host_path,host1g,host95,union950m",
                     help="which of the extra measurements to run (comma separated)")
     args = ap.parse_args()
 
@@ -723,8 +723,28 @@ def main():
                                       "can touch (membership of the mix64 remainder decided from its definition)")
                 r["workload"] = f"configs[1] with a 1 Gbp host genome ({len(hk2):,} of the {int(idx2.n_keys):,} keys are host minimizers)"
                 workloads["host1g"] = r
+                del bs
+                if "host95" in extras:
+                    # the shape of a host-depletion run: 95 % of the reads come from the (1 Gbp) host, `-d` keeps the rest.
+                    # Decisions only is what such a run needs; reads from the host stop being probed after abs_threshold hits
+                    t_9 = time.time()
+                    bs = make_batches("short", g2, args.reads, 17, device, host_frac=0.95)
+                    P_DEPLETE = {"abs": 2, "rel": 0.01, "deplete": True}
+                    r9, _, _, _ = run_device_workload(idx2, bs, P_DEPLETE, 12, 3, 1, device)
+                    b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
+                    small = touchable_oracle_index(b_, o_, hk2, nr2, cores)
+                    keep, hits, total = oracle_decisions(small, b_, o_, u_, P_DEPLETE, cores)
+                    ok9 = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
+                        bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all()) and \
+                        bool((bs[0].d_keep2[:nu_].cpu().numpy().astype(bool) == keep).all())
+                    r9["decisions_match_gpu"] = ok9
+                    r9["oracle_sample"] = f"first {len(o_) - 1} reads of batch 0, counting and decisions-only mode, vs the oracle on the {len(small):,} index keys the sample can touch"
+                    r9["workload"] = "a host-depletion run: 150 bp reads, 95 % from the 1 Gbp host genome, -a 2 -r 0.01 --deplete (5 % kept)"
+                    workloads["host95"] = r9
+                    del bs
+                    log(f"workloads.host95: {r9['value'] / 1e3:.1f} Gbp/s counting, {r9['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, oracle ok={ok9} ({time.time() - t_9:.0f} s)")
                 idx2.close()
-                del bs, g2, hk2
+                del g2, hk2
                 torch.cuda.empty_cache()
                 log(f"workloads.host1g: {r['value'] / 1e3:.1f} Gbp/s counting, scan {r['stage_ms_per_launch']['scan']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
             elif e == "union950m":

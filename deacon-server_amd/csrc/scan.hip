@@ -619,13 +619,15 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             }
             const uint32_t hi_in = (w_in >> (2 * r + 1)) & 1;
             const uint32_t hl = (w_l >> (2 * r + 1)) & 1;
-            fw = rotl32(fw, 1) ^ zprev ^ e.x;
-            rc = rotl32(rc, 31) ^ wprev ^ e.y;
+            // (v_bitop3_b32, one instruction each: a ^ b ^ c = table 0x96; (a & b) | c = 0xEA; (~a & b) | c = 0xAE)
+            fw = __builtin_amdgcn_bitop3_b32(rotl32(fw, 1), zprev, e.x, 0x96);
+            rc = __builtin_amdgcn_bitop3_b32(rotl32(rc, 31), wprev, e.y, 0x96);
             zprev = e.z;
             wprev = e.w;
             const uint32_t h = fw + rc;
-            const uint32_t lk = (h & keymask) | (j & ~keymask);
-            const uint32_t rk = lk ^ 0xFFFF0000u;
+            const uint32_t jlow = j & 0xFFFFu;
+            const uint32_t lk = __builtin_amdgcn_bitop3_b32(h, keymask, jlow, 0xEA);
+            const uint32_t rk = __builtin_amdgcn_bitop3_b32(h, keymask, jlow, 0xAE);
             uint32_t lmin, rmax;
             if constexpr (W > 0) {
                 // two-stack sliding min/max: ring slot r is static because the loop is unrolled by W

@@ -632,8 +632,11 @@ def main():
                 pass
         rf = head["roofline"]
         rf["traffic"] = traffic
-        rf["probe_only_kernel_live_per_s"] = probe_only_rate(index, device)
-        rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
+        try:
+            rf["probe_only_kernel_live_per_s"] = probe_only_rate(index, device)
+            rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
+        except Exception as ex:
+            log(f"probe-only measurement failed: {ex!r}")
         if traffic:
             # measured HBM traffic (PMC) over the live launch time: what the probe kernel really pulls from HBM
             rf["traffic_rate_GBps"] = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9
@@ -665,20 +668,23 @@ def main():
         extras = [] if (args.no_extras or world > 1) else [e for e in args.extras.split(",") if e]
         oidx, cores = None, host_cores()
         need_oracle = (not args.no_cpu_baseline and world == 1) or any(e in extras for e in ("long", "paired", "host_path"))
-        if need_oracle:
-            from oracle import oracle as O
-            t0 = time.time()
-            oidx = O.Index(keys, K, W, threads=cores)
-            log(f"CPU oracle set of {len(oidx):,} keys built with {cores} threads in {time.time() - t0:.1f} s (checker + cpu_baseline)")
-        if world == 1 and not args.no_cpu_baseline and args.workload == "short":
-            out["cpu_baseline"] = cpu_baseline(oidx, cores, batches[0], params)
-            log(f"cpu_baseline: {out['cpu_baseline']['value']:.0f} Mbp/s on {cores} cores, decisions match: {out['cpu_baseline']['decisions_match_gpu']}")
-        elif world == 1 and oidx is not None:
-            ok, what = check_against_oracle(oidx, batches[0], params, 300_000_000, cores)
-            out["cpu_baseline"] = None
-            out["decisions_match_gpu"] = ok
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = None
+        try:
+            if need_oracle:
+                from oracle import oracle as O
+                t0 = time.time()
+                oidx = O.Index(keys, K, W, threads=cores)
+                log(f"CPU oracle set of {len(oidx):,} keys built with {cores} threads in {time.time() - t0:.1f} s (checker + cpu_baseline)")
+            if world == 1 and not args.no_cpu_baseline and args.workload == "short":
+                out["cpu_baseline"] = cpu_baseline(oidx, cores, batches[0], params)
+                log(f"cpu_baseline: {out['cpu_baseline']['value']:.0f} Mbp/s on {cores} cores, decisions match: {out['cpu_baseline']['decisions_match_gpu']}")
+            elif world == 1 and oidx is not None:
+                ok, what = check_against_oracle(oidx, batches[0], params, 300_000_000, cores)
+                out["decisions_match_gpu"] = ok
+        except Exception as ex:  # the checker failing (e.g. no host memory for its key set) must not take the line with it
+            log(f"cpu_baseline / oracle failed: {ex!r}")
+            out["cpu_baseline_error"] = repr(ex)
+            oidx = None
 
         # ---- everything below runs after the contract's timed region and never enters `value` --------------------------
         workloads, host_path = {}, None
@@ -686,87 +692,103 @@ def main():
         del keys
         for e in extras:
             t_e = time.time()
-            if e in ("long", "paired") and e != args.workload:
-                bs = make_batches(e, genome_dev, args.reads, seeds[e], device)
-                p = P_PAIRED if e == "paired" else P_SHORT
-                r, _, _, _ = run_device_workload(index, bs, p, 12, 3, 1, device, reserve_long=e == "long")
-                ok, what = check_against_oracle(oidx, bs[0], p, 200_000_000, cores)
-                r["decisions_match_gpu"], r["oracle_sample"] = ok, what + f" vs the oracle's {len(oidx):,}-key set (keep, hits, totals)"
-                r["workload"] = names[e]
-                workloads[e] = r
-                del bs
-                log(f"workloads.{e}: {r['value'] / 1e3:.1f} Gbp/s counting, {r['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, "
-                    f"scan {r['stage_ms_per_launch']['scan']:.2f} ms, distinct {r['stage_ms_per_launch']['distinct']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
-            elif e == "host_path":
-                if short_batches is None:
-                    short_batches = make_batches("short", genome_dev, 2_000_000, seeds["short"], device)
-                host_path = run_host_path(index, short_batches, P_SHORT, oidx, cores)
+            try:
+                if e in ("long", "paired") and e != args.workload:
+                    bs = make_batches(e, genome_dev, args.reads, seeds[e], device)
+                    p = P_PAIRED if e == "paired" else P_SHORT
+                    r, _, _, _ = run_device_workload(index, bs, p, 12, 3, 1, device, reserve_long=e == "long")
+                    ok, what = check_against_oracle(oidx, bs[0], p, 200_000_000, cores)
+                    r["decisions_match_gpu"], r["oracle_sample"] = ok, what + f" vs the oracle's {len(oidx):,}-key set (keep, hits, totals)"
+                    r["workload"] = names[e]
+                    workloads[e] = r
+                    del bs
+                    log(f"workloads.{e}: {r['value'] / 1e3:.1f} Gbp/s counting, {r['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, "
+                        f"scan {r['stage_ms_per_launch']['scan']:.2f} ms, distinct {r['stage_ms_per_launch']['distinct']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
+                elif e == "host_path":
+                    if short_batches is None:
+                        short_batches = make_batches("short", genome_dev, 2_000_000, seeds["short"], device)
+                    host_path = run_host_path(index, short_batches, P_SHORT, oidx, cores)
+            except Exception as ex:  # an extra that fails must not take the contract's line with it
+                log(f"extra '{e}' failed: {ex!r}")
+                if e == "host_path":
+                    host_path = {"error": repr(ex)}
+                else:
+                    workloads[e] = {"error": repr(ex)}
+                torch.cuda.empty_cache()
         if oidx is not None:
             del oidx
         torch.cuda.empty_cache()
         for e in extras:
             t_e = time.time()
-            if e == "host1g":
-                # sensitivity point: a >= 1 Gbp host genome (a real 3 Gbp host leaves far fewer of a batch's probes in cache)
-                g2 = make_host_genome(1_000_000_000, 13, device)
-                idx2, keys2, hk2, nr2, _ = build_index(g2, args.index_keys, local_rank)
-                del keys2
-                bs = make_batches("short", g2, args.reads, 15, device)
-                r, _, _, _ = run_device_workload(idx2, bs, P_SHORT, 12, 3, 1, device)
-                b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
-                small = touchable_oracle_index(b_, o_, hk2, nr2, cores)
-                keep, hits, total = oracle_decisions(small, b_, o_, u_, P_SHORT, cores)
-                ok = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
-                    bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all())
-                r["decisions_match_gpu"] = ok
-                r["oracle_sample"] = (f"first {len(o_) - 1} reads of batch 0 vs the oracle on the {len(small):,} index keys the sample "
-                                      "can touch (membership of the mix64 remainder decided from its definition)")
-                r["workload"] = f"configs[1] with a 1 Gbp host genome ({len(hk2):,} of the {int(idx2.n_keys):,} keys are host minimizers)"
-                workloads["host1g"] = r
-                del bs
-                if "host95" in extras:
-                    # the shape of a host-depletion run: 95 % of the reads come from the (1 Gbp) host, `-d` keeps the rest.
-                    # Decisions only is what such a run needs; reads from the host stop being probed after abs_threshold hits
-                    t_9 = time.time()
-                    bs = make_batches("short", g2, args.reads, 17, device, host_frac=0.95)
-                    P_DEPLETE = {"abs": 2, "rel": 0.01, "deplete": True}
-                    r9, _, _, _ = run_device_workload(idx2, bs, P_DEPLETE, 12, 3, 1, device)
+            try:
+                if e == "host1g":
+                    # sensitivity point: a >= 1 Gbp host genome (a real 3 Gbp host leaves far fewer of a batch's probes in cache)
+                    g2 = make_host_genome(1_000_000_000, 13, device)
+                    idx2, keys2, hk2, nr2, _ = build_index(g2, args.index_keys, local_rank)
+                    del keys2
+                    bs = make_batches("short", g2, args.reads, 15, device)
+                    r, _, _, _ = run_device_workload(idx2, bs, P_SHORT, 12, 3, 1, device)
                     b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
                     small = touchable_oracle_index(b_, o_, hk2, nr2, cores)
-                    keep, hits, total = oracle_decisions(small, b_, o_, u_, P_DEPLETE, cores)
-                    ok9 = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
-                        bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all()) and \
-                        bool((bs[0].d_keep2[:nu_].cpu().numpy().astype(bool) == keep).all())
-                    r9["decisions_match_gpu"] = ok9
-                    r9["oracle_sample"] = f"first {len(o_) - 1} reads of batch 0, counting and decisions-only mode, vs the oracle on the {len(small):,} index keys the sample can touch"
-                    r9["workload"] = "a host-depletion run: 150 bp reads, 95 % from the 1 Gbp host genome, -a 2 -r 0.01 --deplete (5 % kept)"
-                    workloads["host95"] = r9
+                    keep, hits, total = oracle_decisions(small, b_, o_, u_, P_SHORT, cores)
+                    ok = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
+                        bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all())
+                    r["decisions_match_gpu"] = ok
+                    r["oracle_sample"] = (f"first {len(o_) - 1} reads of batch 0 vs the oracle on the {len(small):,} index keys the sample "
+                                          "can touch (membership of the mix64 remainder decided from its definition)")
+                    r["workload"] = f"configs[1] with a 1 Gbp host genome ({len(hk2):,} of the {int(idx2.n_keys):,} keys are host minimizers)"
+                    workloads["host1g"] = r
                     del bs
-                    log(f"workloads.host95: {r9['value'] / 1e3:.1f} Gbp/s counting, {r9['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, oracle ok={ok9} ({time.time() - t_9:.0f} s)")
-                idx2.close()
-                del g2, hk2
+                    if "host95" in extras:
+                        # the shape of a host-depletion run: 95 % of the reads come from the (1 Gbp) host, `-d` keeps the rest.
+                        # Decisions only is what such a run needs; reads from the host stop being probed after abs_threshold hits
+                        t_9 = time.time()
+                        bs = make_batches("short", g2, args.reads, 17, device, host_frac=0.95)
+                        P_DEPLETE = {"abs": 2, "rel": 0.01, "deplete": True}
+                        r9, _, _, _ = run_device_workload(idx2, bs, P_DEPLETE, 12, 3, 1, device)
+                        b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
+                        small = touchable_oracle_index(b_, o_, hk2, nr2, cores)
+                        keep, hits, total = oracle_decisions(small, b_, o_, u_, P_DEPLETE, cores)
+                        ok9 = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
+                            bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all()) and \
+                            bool((bs[0].d_keep2[:nu_].cpu().numpy().astype(bool) == keep).all())
+                        r9["decisions_match_gpu"] = ok9
+                        r9["oracle_sample"] = f"first {len(o_) - 1} reads of batch 0, counting and decisions-only mode, vs the oracle on the {len(small):,} index keys the sample can touch"
+                        r9["workload"] = "a host-depletion run: 150 bp reads, 95 % from the 1 Gbp host genome, -a 2 -r 0.01 --deplete (5 % kept)"
+                        workloads["host95"] = r9
+                        del bs
+                        log(f"workloads.host95: {r9['value'] / 1e3:.1f} Gbp/s counting, {r9['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, oracle ok={ok9} ({time.time() - t_9:.0f} s)")
+                    idx2.close()
+                    del g2, hk2
+                    torch.cuda.empty_cache()
+                    log(f"workloads.host1g: {r['value'] / 1e3:.1f} Gbp/s counting, scan {r['stage_ms_per_launch']['scan']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
+                elif e == "union950m":
+                    index.close()
+                    idx3, keys3, hk3, nr3, tb = build_index(genome_dev, UNION_KEYS, local_rank)
+                    del keys3
+                    bs = make_batches("paired", genome_dev, args.reads, 27, device)
+                    r, _, _, _ = run_device_workload(idx3, bs, P_PAIRED, 12, 3, 1, device)
+                    b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
+                    small = touchable_oracle_index(b_, o_, hk3, nr3, cores)
+                    keep, hits, total = oracle_decisions(small, b_, o_, u_, P_PAIRED, cores)
+                    ok = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
+                        bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all())
+                    r["decisions_match_gpu"] = ok
+                    r["oracle_sample"] = (f"first {len(o_) - 1} reads of batch 0 vs the oracle on the {len(small):,} index keys the sample "
+                                          "can touch (membership of the mix64 remainder decided from its definition)")
+                    r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB), paired 2x150 bp --deplete"
+                    r["table_build_s"] = tb
+                    workloads["union950m"] = r
+                    idx3.close()
+                    index = None
+                    log(f"workloads.union950m: {r['value'] / 1e3:.1f} Gbp/s counting, scan {r['stage_ms_per_launch']['scan']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
+            except Exception as ex:  # an extra that fails must not take the contract's line with it
+                log(f"extra '{e}' failed: {ex!r}")
+                if e == "host_path":
+                    host_path = {"error": repr(ex)}
+                else:
+                    workloads[e] = {"error": repr(ex)}
                 torch.cuda.empty_cache()
-                log(f"workloads.host1g: {r['value'] / 1e3:.1f} Gbp/s counting, scan {r['stage_ms_per_launch']['scan']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
-            elif e == "union950m":
-                index.close()
-                idx3, keys3, hk3, nr3, tb = build_index(genome_dev, UNION_KEYS, local_rank)
-                del keys3
-                bs = make_batches("paired", genome_dev, args.reads, 27, device)
-                r, _, _, _ = run_device_workload(idx3, bs, P_PAIRED, 12, 3, 1, device)
-                b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
-                small = touchable_oracle_index(b_, o_, hk3, nr3, cores)
-                keep, hits, total = oracle_decisions(small, b_, o_, u_, P_PAIRED, cores)
-                ok = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
-                    bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all())
-                r["decisions_match_gpu"] = ok
-                r["oracle_sample"] = (f"first {len(o_) - 1} reads of batch 0 vs the oracle on the {len(small):,} index keys the sample "
-                                      "can touch (membership of the mix64 remainder decided from its definition)")
-                r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB), paired 2x150 bp --deplete"
-                r["table_build_s"] = tb
-                workloads["union950m"] = r
-                idx3.close()
-                index = None
-                log(f"workloads.union950m: {r['value'] / 1e3:.1f} Gbp/s counting, scan {r['stage_ms_per_launch']['scan']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
         if workloads:
             out["workloads"] = workloads
         if host_path:

@@ -395,7 +395,7 @@ struct dcn_ctx {
     uint64_t next_ticket = 1;
     // dump mode buffers (lazy)
     uint64_t *d_dump_hash = nullptr;
-    uint32_t *d_dump_pos = nullptr, *d_dump_count = nullptr;
+    uint32_t *d_dump_pos = nullptr, *d_dump_count = nullptr, *d_tile_read_pos = nullptr;
     uint8_t *d_dump_valid = nullptr;
     // deferred state of the last enqueued device-API batch
     bool batch_pending = false;
@@ -468,7 +468,7 @@ void free_ctx(dcn_ctx *c) {
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
                    c->d_keep, c->d_unit_state, c->d_hits, c->d_total, c->d_unit_scratch, c->d_caps,
                    c->d_set_off, c->d_tile_hits, c->d_pending, c->d_big, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
-                   c->d_dump_pos, c->d_dump_count, c->d_dump_valid};
+                   c->d_dump_pos, c->d_dump_count, c->d_dump_valid, c->d_tile_read_pos};
     for (void *p : dev)
         if (p) hipFree(p);
     for (int i = 0; i < dcn_ctx::N_STAGE; ++i) {
@@ -1685,6 +1685,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
         DCN_TRY(dev_alloc(&c->d_dump_valid, c->max_bases + 2, "dump_valid"));
         DCN_TRY(dev_alloc(&c->d_dump_count, c->max_tiles, "dump_count"));
     }
+    if (!c->d_tile_read_pos) DCN_TRY(dev_alloc(&c->d_tile_read_pos, c->max_tiles, "tile_read_pos"));
     DCN_TRY(staged_h2d(c, c->d_ascii, bases, n_bases));
     DCN_TRY(staged_h2d(c, c->d_offsets, offsets, (uint64_t)(n_reads + 1) * sizeof(uint64_t)));
     DCN_HIP(hipEventRecord(c->copy_done, c->copy_stream));
@@ -1710,6 +1711,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     pa.unit_tile_count = c->d_unit_tile_count;
     pa.tile_cursor = &c->d_status->n_tiles;
     pa.tiles = c->d_tiles;
+    pa.tile_read_pos = c->d_tile_read_pos;
     pa.status = c->d_status;
     DCN_TRY(dcn_launch_plan(pa, st));
     dcn_scan_args sa;
@@ -1717,6 +1719,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     sa.packed = packed;
     sa.invmask = invmask;
     sa.tiles = c->d_tiles;
+    sa.tile_read_pos = c->d_tile_read_pos;
     sa.n_tiles = &c->d_status->n_tiles;
     sa.table = c->index->view();
     sa.k = c->index->k;
@@ -1752,7 +1755,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     uint64_t n_out = 0;
     for (uint32_t r = 0; r < n_reads; ++r) {
         for (uint32_t t = rtf[r]; t < rtf[r] + rtn[r]; ++t) {
-            uint64_t base = tiles[t].scan_start + (tiles[t].flags & 1u);
+            uint64_t base = tiles[t].scan_start + tiles[t].carry();
             for (uint32_t e = 0; e < tcount[t]; ++e) {
                 if (!v[base + e]) continue;
                 if (n_out < capacity) {
@@ -1929,14 +1932,12 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             pa.w = idx->w;
             pa.prefix_length = 0;
             pa.tile_windows = c->tile_windows;
-                    pa.read_tiles = c->d_read_tiles;
+            pa.read_tiles = c->d_read_tiles;
             pa.read_tile_first = c->d_read_tile_first;
             pa.unit_first_read = c->d_unit_first_read;
             pa.unit_tile_first = c->d_unit_tile_first;
             pa.unit_tile_count = c->d_unit_tile_count;
             pa.tile_cursor = &c->d_status->n_tiles;
-    pa.unit_tile_count = c->d_unit_tile_count;
-    pa.tile_cursor = &c->d_status->n_tiles;
             pa.tiles = c->d_tiles;
             pa.status = c->d_status;
             DCN_TRY(dcn_launch_plan(pa, st));

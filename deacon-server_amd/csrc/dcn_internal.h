@@ -87,13 +87,17 @@ constexpr uint32_t DCN_TAIL_PAD = 256; // u32 words after it (lanes over-read pa
 constexpr uint32_t DCN_MAX_TILE_WINDOWS = 2048;
 
 // one tile = up to `tile_windows` consecutive windows of one read, scanned by one lane
+// (16 bytes: one dwordx4 per lane of the scan kernel, whose time is its L2 misses -- DESIGN.md section 6.2.  The
+// position of scan_start inside its read, which only the minimizer dump reports, lives in a side array.)
 struct dcn_tile {
     uint64_t scan_start; // absolute base index (in the batch stream) of the first base to scan
-    uint32_t read_pos;   // position in the read of scan_start (for reporting positions)
     uint32_t unit;       // global unit id
-    uint32_t n_windows;  // windows whose minimizers this tile emits
-    uint32_t flags;      // bit0: has carry window (first scanned window only seeds the dedup state)
+    uint32_t nwf;        // bits 0..30: windows whose minimizers this tile emits; bit 31: has a carry window (the first
+                         // scanned window only seeds the dedup state)
+    __host__ __device__ uint32_t n_windows() const { return nwf & 0x7FFFFFFFu; }
+    __host__ __device__ uint32_t carry() const { return nwf >> 31; }
 };
+static_assert(sizeof(dcn_tile) == 16, "tile descriptor");
 
 // status words written by the device pipeline (one per ctx, zeroed before every enqueued batch / chunk)
 struct dcn_status {
@@ -122,6 +126,7 @@ struct dcn_scan_args {
     const uint32_t *packed; // 2-bit stream, already offset by DCN_FRONT_PAD words
     const uint32_t *invmask; // 1 bit per base, same padding (in 32-bit words)
     const dcn_tile *tiles;
+    const uint32_t *tile_read_pos; // dump mode with read-relative positions: position of scan_start in its read
     const uint32_t *n_tiles; // device-side tile count
     const uint32_t *unit_tile_first; // n_units: first tile index of each unit
     const uint32_t *unit_tile_count; // n_units: number of tiles, 0xFFFFFFFF when they are not contiguous

@@ -21,6 +21,7 @@ struct dcn_plan_args {
     uint32_t *unit_scratch;     // g_total | g_hitcnt | g_distinct | g_zero, scratch_stride entries each, cleared here
     uint32_t scratch_stride;
     dcn_tile *tiles;
+    uint32_t *tile_read_pos; // null, or per tile the position of its scan_start in its read (minimizer dump)
     uint32_t *tile_cursor;      // global tile counter (= &status->n_tiles, zeroed per batch)
     dcn_status *status;
 };

@@ -23,11 +23,10 @@ __device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32
     uint32_t carry = j > 0 ? 1u : 0u;
     dcn_tile t;
     t.scan_start = off + wstart - carry;
-    t.read_pos = wstart - carry;
     t.unit = unit;
-    t.n_windows = min(a.tile_windows, nwin - wstart);
-    t.flags = carry;
+    t.nwf = min(a.tile_windows, nwin - wstart) | (carry << 31);
     a.tiles[first + j] = t;
+    if (a.tile_read_pos) a.tile_read_pos[first + j] = wstart - carry;
 }
 
 // One launch plans the whole batch.  A workgroup takes PLAN_READS consecutive reads (8 per thread): effective lengths
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
             if (t < count) {
                 n = a.tile_hits[first + t];
                 const dcn_tile tl = a.tiles[first + t];
-                slot0 = tl.scan_start + (tl.flags & 1u);
+                slot0 = tl.scan_start + tl.carry();
             }
         };
         uint32_t n;
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
         if (t < count) {
             n = a.tile_hits[first + t];
             const dcn_tile tl = a.tiles[first + t];
-            slot0 = tl.scan_start + (tl.flags & 1u);
+            slot0 = tl.scan_start + tl.carry();
         }
         uint32_t fresh_n = 0;
         unsigned long long runs = __ballot(n != 0);
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
         const uint32_t cap = a.caps[tl.unit];
         const uint32_t n = a.tile_hits[t];
         if (!cap || !n) continue;
-        const uint32_t fresh_n = insert_run(a.rec_hash, tl.scan_start + (tl.flags & 1u), n,
+        const uint32_t fresh_n = insert_run(a.rec_hash, tl.scan_start + tl.carry(), n,
                                             (unsigned long long *)(a.set_slots + a.set_off[tl.unit]), cap, lane);
         if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[tl.unit], fresh_n);
     }
@@ -487,10 +486,8 @@ __global__ __launch_bounds__(256) void hash_units_kernel(dcn_probe_hashes_args a
     const uint64_t n = a.hash_offsets[u + 1] - a.hash_offsets[u];
     dcn_tile t;
     t.scan_start = a.hash_offsets[u];
-    t.read_pos = 0;
     t.unit = u;
-    t.n_windows = (uint32_t)n;
-    t.flags = 0;
+    t.nwf = (uint32_t)n & 0x7FFFFFFFu; // (the run length travels in tile_hits; no scan ever reads this field here)
     a.tiles[u] = t;
     a.tile_hits[u] = (uint32_t)n;
     a.unit_tile_first[u] = u;

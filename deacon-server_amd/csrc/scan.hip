@@ -138,9 +138,10 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     const uint32_t tile_idx = wave_first + lane;
     const bool have_tile = tile_idx < NT;
     dcn_tile t = a.tiles[have_tile ? tile_idx : NT - 1];
-    if (!have_tile) t.n_windows = 0;
-    const uint32_t carry = t.flags & 1u;
-    const uint32_t nwc = t.n_windows ? t.n_windows + carry : 0; // windows this lane evaluates
+    if (!have_tile) t.nwf = 0;
+    const uint32_t carry = t.carry();
+    const uint32_t nwc = t.n_windows() ? t.n_windows() + carry : 0; // windows this lane evaluates
+    const uint32_t tile_read_pos = (DUMP && have_tile && a.tile_read_pos) ? a.tile_read_pos[tile_idx] : 0u;
     const uint32_t unit_prev = __shfl_up(t.unit, 1, 64);
     const uint64_t start_prev = (uint64_t)__shfl_up((long long)t.scan_start, 1, 64);
     // A unit slot is a run of adjacent lanes of one unit IN STREAM ORDER.  Tiles follow the stream inside a planning
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     sh.uhits[lane] = 0;
     if (head) {
         sh.unit_of[uslot] = t.unit;
-        sh.run_base[uslot] = t.scan_start + (t.flags & 1u);
+        sh.run_base[uslot] = t.scan_start + carry;
         bool loc = false;
         if (!DUMP) {
             uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     uint32_t o_eb = __shfl(emitted_before, lo[u], 64);
-                    uint32_t o_rp = __shfl(t.read_pos, lo[u], 64);
+                    uint32_t o_rp = __shfl(tile_read_pos, lo[u], 64);
                     uint32_t o_carry = __shfl(carry, lo[u], 64);
                     long long o_s = __shfl((long long)s, lo[u], 64);
                     if (act[u]) {

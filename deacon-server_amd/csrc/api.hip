@@ -374,7 +374,8 @@ struct dcn_ctx {
     // per-unit results / scratch
     uint8_t *d_keep = nullptr, *d_unit_state = nullptr;
     uint32_t *d_hits = nullptr, *d_total = nullptr;
-    uint32_t *d_unit_scratch = nullptr; // g_total | g_hitcnt | g_distinct | g_zero, max_reads each
+    uint32_t *d_unit_scratch = nullptr; // g_total | g_hitcnt | g_distinct | g_zero, max_reads each; zero between batches
+    bool scratch_dirty = false;         // a run was enqueued up to, but not including, its finish kernel
     uint32_t *d_caps = nullptr, *d_set_off = nullptr;
     // hit records + distinct sets
     // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
@@ -558,6 +559,10 @@ struct BatchView {
 int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     hipStream_t st = c->stream;
     const dcn_index *idx = c->index;
+    // the per-unit scratch words are zero between batches (finish_kernel leaves them so); a run that did not get as
+    // far as enqueueing its finish kernel may have left some behind
+    if (c->scratch_dirty) DCN_HIP(hipMemsetAsync(c->d_unit_scratch, 0, (uint64_t)c->max_reads * 4 * sizeof(uint32_t), st));
+    c->scratch_dirty = true;
     // per-run scratch: the status words (the per-unit state and scratch words are cleared by the plan kernel)
     DCN_HIP(hipMemsetAsync(c->d_status, 0, sizeof(dcn_status), st));
 
@@ -667,6 +672,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     fa.offsets = v.d_offsets;
     fa.unit_state = c->d_unit_state;
     fa.g_total = g_total;
+    fa.g_hitcnt = g_hitcnt;
     fa.g_distinct = g_distinct;
     fa.g_zero = g_zero;
     fa.abs_threshold = params->abs_threshold;
@@ -678,6 +684,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     fa.report = v.d_report;
     fa.status = c->d_status;
     DCN_TRY(dcn_launch_finish(fa, st));
+    c->scratch_dirty = false;
     DCN_PROF_MARK(DCN_STAGE_FINISH);
     if (prof_slot >= 0) c->prof_used[prof_slot] = true;
     return DCN_OK;
@@ -1058,6 +1065,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     if (hipMemset(c->d_packed, 0, packed_words(max_batch_bases) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->d_invmask, 0, mask_words(max_batch_bases) * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->d_status, 0, sizeof(dcn_status)) != hipSuccess ||
+        hipMemset(c->d_unit_scratch, 0, (uint64_t)max_batch_reads * 4 * sizeof(uint32_t)) != hipSuccess ||
         hipMemset(c->d_report, 0, sizeof(dcn_batch_report)) != hipSuccess ||
         // hipMemset runs on the null stream and does not wait for the host; the context's streams are non-blocking
         // and do not wait for the null stream: without this, the first batch's copies into the packed stream can
@@ -1853,6 +1861,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         fa.offsets = nullptr; // no read lengths here: the counters are untouched
         fa.unit_state = c->d_unit_state;
         fa.g_total = g_total;
+        fa.g_hitcnt = g_hitcnt;
         fa.g_distinct = g_distinct;
         fa.g_zero = g_zero;
         fa.abs_threshold = params->abs_threshold;

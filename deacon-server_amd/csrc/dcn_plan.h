@@ -18,7 +18,7 @@ struct dcn_plan_args {
     uint32_t *unit_tile_first;  // n_units: first tile of the unit
     uint32_t *unit_tile_count;  // n_units: its tile count; 0xFFFFFFFF = tiles not contiguous (never resolved in-wave)
     uint8_t *unit_state;        // n_units, cleared here (1 = resolved by the scan kernel)
-    uint32_t *unit_scratch;     // g_total | g_hitcnt | g_distinct | g_zero, scratch_stride entries each, cleared here
+    uint32_t *unit_scratch;     // g_total | g_hitcnt | g_distinct | g_zero, scratch_stride entries each (zero between batches: finish_kernel)
     uint32_t scratch_stride;
     dcn_tile *tiles;
     uint32_t *tile_read_pos; // null, or per tile the position of its scan_start in its read (minimizer dump)
@@ -51,7 +51,7 @@ struct dcn_finish_args {
     const uint32_t *unit_first_read; // null: unit == read
     const uint64_t *offsets;         // null: no counters (hash seam)
     const uint8_t *unit_state;
-    const uint32_t *g_total, *g_distinct, *g_zero;
+    uint32_t *g_total, *g_hitcnt, *g_distinct, *g_zero; // read for undecided units, and put back to zero
     uint64_t abs_threshold;
     double rel_threshold;
     uint32_t deplete;

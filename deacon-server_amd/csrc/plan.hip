@@ -123,12 +123,10 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
             }
             a.unit_tile_first[u] = first;
             a.unit_tile_count[u] = count;
-            // per-unit scratch of this batch starts from zero (saves two memset launches per batch)
-            if (a.unit_state) { // null for the minimizer dump / index build, which keep no per-unit state
-                a.unit_state[u] = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) a.unit_scratch[(uint64_t)q * a.scratch_stride + u] = 0;
-            }
+            // (the four scratch words per unit -- g_total, g_hitcnt, g_distinct, g_zero -- are zero between batches:
+            // finish_kernel puts back to zero what a batch touched, which for short reads is next to nothing, instead of
+            // 16 bytes per unit being written here)
+            if (a.unit_state) a.unit_state[u] = 0; // null for the minimizer dump / index build, which keep no per-unit state
         }
         const uint64_t off = a.offsets[r];
         for (uint32_t j = 0; j < min(nt[c], OWN); ++j) write_tile(a, first, j, off, nwin[c], u);
@@ -405,6 +403,11 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
                 keep = kept[q] != 0;
             } else {
                 uint32_t tot = a.g_total[u], hc = a.g_distinct[u] + (a.g_zero[u] ? 1u : 0u);
+                // this unit went through the global scratch words: leave them zero for the next batch
+                a.g_total[u] = 0;
+                a.g_hitcnt[u] = 0;
+                a.g_distinct[u] = 0;
+                a.g_zero[u] = 0;
                 keep = dcn_decide(hc, tot, a.abs_threshold, a.rel_threshold, a.deplete);
                 a.keep[u] = keep ? 1 : 0;
                 if (a.hits) a.hits[u] = hc;

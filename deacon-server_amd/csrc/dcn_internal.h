@@ -92,10 +92,13 @@ constexpr uint32_t DCN_MAX_TILE_WINDOWS = 2048;
 struct dcn_tile {
     uint64_t scan_start; // absolute base index (in the batch stream) of the first base to scan
     uint32_t unit;       // global unit id
-    uint32_t nwf;        // bits 0..30: windows whose minimizers this tile emits; bit 31: has a carry window (the first
-                         // scanned window only seeds the dedup state)
-    __host__ __device__ uint32_t n_windows() const { return nwf & 0x7FFFFFFFu; }
+    uint32_t nwf;        // bits 0..29: windows whose minimizers this tile emits; bit 31: has a carry window (the first
+                         // scanned window only seeds the dedup state); bit 30: this tile is its unit's only tile and
+                         // unit == read -- such a unit has no entry in unit_tile_first / unit_tile_count unless the
+                         // scan kernel hands it to the distinct pass (it then writes the entry itself)
+    __host__ __device__ uint32_t n_windows() const { return nwf & 0x3FFFFFFFu; }
     __host__ __device__ uint32_t carry() const { return nwf >> 31; }
+    __host__ __device__ bool whole_unit() const { return (nwf >> 30) & 1u; }
 };
 static_assert(sizeof(dcn_tile) == 16, "tile descriptor");
 
@@ -128,8 +131,8 @@ struct dcn_scan_args {
     const dcn_tile *tiles;
     const uint32_t *tile_read_pos; // dump mode with read-relative positions: position of scan_start in its read
     const uint32_t *n_tiles; // device-side tile count
-    const uint32_t *unit_tile_first; // n_units: first tile index of each unit
-    const uint32_t *unit_tile_count; // n_units: number of tiles, 0xFFFFFFFF when they are not contiguous
+    uint32_t *unit_tile_first; // n_units: first tile index of each unit (no entry for whole-unit tiles, see dcn_tile)
+    uint32_t *unit_tile_count; // n_units: number of tiles, 0xFFFFFFFF when they are not contiguous
     dcn_table_view table;
     uint32_t k, w;
     uint64_t stream_bases; // bases of the packed stream (checked by DCN_DEBUG_BOUNDS builds only)

@@ -18,13 +18,13 @@ __device__ inline uint32_t effective_windows(const uint8_t *ascii, uint64_t off,
 }
 
 __device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32_t j, uint64_t off, uint32_t nwin,
-                                  uint32_t unit) {
+                                  uint32_t unit, bool whole_unit = false) {
     uint32_t wstart = j * a.tile_windows;
     uint32_t carry = j > 0 ? 1u : 0u;
     dcn_tile t;
     t.scan_start = off + wstart - carry;
     t.unit = unit;
-    t.nwf = min(a.tile_windows, nwin - wstart) | (carry << 31);
+    t.nwf = min(a.tile_windows, nwin - wstart) | (carry << 31) | (whole_unit ? 1u << 30 : 0u);
     a.tiles[first + j] = t;
     if (a.tile_read_pos) a.tile_read_pos[first + j] = wstart - carry;
 }
@@ -121,15 +121,19 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
                     ++q;
                 }
             }
-            a.unit_tile_first[u] = first;
-            a.unit_tile_count[u] = count;
+            // a read that is a unit of its own with a single tile (every short read) carries that fact in its tile:
+            // 8 bytes per unit less to write here, and to read for the scan kernel
+            if (a.unit_id || nt[c] != 1) {
+                a.unit_tile_first[u] = first;
+                a.unit_tile_count[u] = count;
+            }
             // (the four scratch words per unit -- g_total, g_hitcnt, g_distinct, g_zero -- are zero between batches:
             // finish_kernel puts back to zero what a batch touched, which for short reads is next to nothing, instead of
             // 16 bytes per unit being written here)
             if (a.unit_state) a.unit_state[u] = 0; // null for the minimizer dump / index build, which keep no per-unit state
         }
         const uint64_t off = a.offsets[r];
-        for (uint32_t j = 0; j < min(nt[c], OWN); ++j) write_tile(a, first, j, off, nwin[c], u);
+        for (uint32_t j = 0; j < min(nt[c], OWN); ++j) write_tile(a, first, j, off, nwin[c], u, !a.unit_id && nt[c] == 1);
         if (nt[c] > OWN) long_reads[atomicAdd(&n_long, 1u)] = c * 256 + tid;
     }
     __syncthreads();
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256) void hash_units_kernel(dcn_probe_hashes_args a
     dcn_tile t;
     t.scan_start = a.hash_offsets[u];
     t.unit = u;
-    t.nwf = (uint32_t)n & 0x7FFFFFFFu; // (the run length travels in tile_hits; no scan ever reads this field here)
+    t.nwf = (uint32_t)n & 0x3FFFFFFFu; // (the run length travels in tile_hits; no scan ever reads this field here)
     a.tiles[u] = t;
     a.tile_hits[u] = (uint32_t)n;
     a.unit_tile_first[u] = u;

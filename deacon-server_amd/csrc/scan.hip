@@ -162,8 +162,12 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
         sh.run_base[uslot] = t.scan_start + carry;
         bool loc = false;
         if (!DUMP) {
-            uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
-            loc = count != 0xFFFFFFFFu && first >= wave_first && first + count <= wave_first + DCN_WAVE;
+            if (t.whole_unit()) { // the unit's only tile is this lane's
+                loc = true;
+            } else {
+                uint32_t first = a.unit_tile_first[t.unit], count = a.unit_tile_count[t.unit];
+                loc = count != 0xFFFFFFFFu && first >= wave_first && first + count <= wave_first + DCN_WAVE;
+            }
         }
         sh.local[uslot] = loc ? 1 : 0;
     }
@@ -856,7 +860,13 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&a.status->n_pending, (uint32_t)__popcll(em));
             base = __shfl(base, 0, 64);
-            if (enrol) a.pending[base + (uint32_t)__popcll(em & ((1ull << lane) - 1))] = t.unit;
+            if (enrol) {
+                a.pending[base + (uint32_t)__popcll(em & ((1ull << lane) - 1))] = t.unit;
+                if (t.whole_unit()) { // (more hits than the in-wave ring holds) the plan kernel left no tile range for it
+                    a.unit_tile_first[t.unit] = tile_idx;
+                    a.unit_tile_count[t.unit] = 1;
+                }
+            }
         }
     }
 

@@ -182,31 +182,27 @@ class Input {
 };
 
 // ---- output: plain, gzip, zstd or xz by extension (get_writer, src/local_filter.rs:110-151) ---------------------------
+// Compressed outputs are written as a sequence of complete members (gzip members, zstd frames, xz streams), one per
+// batch: concatenations of those are valid files of their formats (what pigz / bgzip / `cat a.zst b.zst` produce), and
+// a member depends on nothing but its own bytes -- so the formatter threads compress their batches side by side and
+// the writer only appends, where the reference's single encoder (get_writer, src/local_filter.rs:110-151) compresses
+// on one thread.
 class Output {
   public:
-    Output(const std::string &path, int level) {
+    enum Codec { PLAIN, GZIP, ZSTD, XZ };
+    Output(const std::string &path, int level) : level_(level) {
         std::string why;
         if (ends_with(path, ".gz")) {
             if (level < 1 || level > 9) die("Invalid gzip compression level " + std::to_string(level) + ". Must be between 1 and 9.");
-            std::string mode = "wb" + std::to_string(level);
-            gz_ = gzopen(path.c_str(), mode.c_str());
-            if (!gz_) die("Failed to create output file: " + path);
-            gzbuffer(gz_, 1 << 20);
-            return;
-        }
-        if (ends_with(path, ".zst")) {
+            codec_ = GZIP;
+        } else if (ends_with(path, ".zst")) {
             if (level < 1 || level > 22) die("Invalid zstd compression level " + std::to_string(level) + ". Must be between 1 and 22.");
-            zstd_ = codecs::Zstd::get(&why);
-            if (!zstd_) die("zstd output " + path + ": " + why);
-            zcs_ = zstd_->createCStream();
-            if (!zcs_ || zstd_->isError(zstd_->initCStream(zcs_, level))) die("zstd initialisation failed");
+            if (!codecs::Zstd::get(&why)) die("zstd output " + path + ": " + why);
+            codec_ = ZSTD;
         } else if (ends_with(path, ".xz")) {
             if (level < 0 || level > 9) die("Invalid xz compression level " + std::to_string(level) + ". Must be between 0 and 9.");
-            lzma_ = codecs::Lzma::get(&why);
-            if (!lzma_) die("xz output " + path + ": " + why);
-            std::memset(&ls_, 0, sizeof ls_);
-            if (lzma_->easy_encoder(&ls_, (uint32_t)level, codecs::LZMA_CHECK_CRC64) != codecs::LZMA_OK) die("xz initialisation failed");
-            xz_ = true;
+            if (!codecs::Lzma::get(&why)) die("xz output " + path + ": " + why);
+            codec_ = XZ;
         }
         if (path == "-") {
             f_ = stdout;
@@ -216,34 +212,103 @@ class Output {
             own_ = true;
         }
         std::setvbuf(f_, nullptr, _IONBF, 0);  // batches arrive as multi-megabyte buffers: no second copy
-        if (zcs_ || xz_) cbuf_.resize(1 << 20);
     }
     ~Output() { close(); }
-    void write(const std::vector<char> &buf) {
-        if (buf.empty()) return;
-        if (gz_) {
-            if (gzwrite(gz_, buf.data(), (unsigned)buf.size()) != (int)buf.size()) die("write error");
-        } else if (zcs_) {
-            codecs::ZSTD_inBuffer in = {buf.data(), buf.size(), 0};
-            while (in.pos < in.size) {
-                codecs::ZSTD_outBuffer out = {cbuf_.data(), cbuf_.size(), 0};
-                if (zstd_->isError(zstd_->compressStream(zcs_, &out, &in))) die("write error: zstd");
-                raw_write(cbuf_.data(), out.pos);
+    Codec codec() const { return codec_; }
+    int level() const { return level_; }
+    bool plain() const { return codec_ == PLAIN; }
+
+    // one complete member of `codec` holding `in` (thread-safe: every call has its own encoder)
+    static void compress_member(Codec codec, int level, const char *in, size_t n, std::vector<char> &out) {
+        out.clear();
+        if (codec == GZIP) {
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("gzip initialisation failed");
+            out.resize(deflateBound(&zs, (uLong)std::min<size_t>(n, 1u << 30)) + (n >> 10) + 64);  // grown below if short
+            size_t in_pos = 0;
+            for (;;) {
+                const size_t take = std::min<size_t>(n - in_pos, 1u << 30);
+                zs.next_in = (Bytef *)(in + in_pos);
+                zs.avail_in = (uInt)take;
+                const bool last = in_pos + take == n;
+                int r = Z_OK;
+                do {
+                    if (zs.total_out == out.size()) out.resize(out.size() * 2 + 4096);
+                    zs.next_out = (Bytef *)out.data() + zs.total_out;
+                    zs.avail_out = (uInt)std::min<size_t>(out.size() - zs.total_out, 1u << 30);
+                    r = deflate(&zs, last ? Z_FINISH : Z_NO_FLUSH);
+                    if (r == Z_STREAM_ERROR) die("write error: gzip");
+                } while (zs.avail_in || (last && r != Z_STREAM_END));
+                in_pos += take;
+                if (last) break;
             }
-        } else if (xz_) {
-            ls_.next_in = (const uint8_t *)buf.data();
-            ls_.avail_in = buf.size();
-            while (ls_.avail_in) {
-                ls_.next_out = (uint8_t *)cbuf_.data();
-                ls_.avail_out = cbuf_.size();
-                if (lzma_->code(&ls_, codecs::LZMA_RUN) != codecs::LZMA_OK) die("write error: xz");
-                raw_write(cbuf_.data(), cbuf_.size() - ls_.avail_out);
+            out.resize(zs.total_out);
+            deflateEnd(&zs);
+        } else if (codec == ZSTD) {
+            const codecs::Zstd *z = codecs::Zstd::get(nullptr);
+            void *cs = z ? z->createCStream() : nullptr;
+            if (!cs || z->isError(z->initCStream(cs, level))) die("zstd initialisation failed");
+            out.resize(n / 2 + (1 << 16));
+            size_t pos = 0;
+            codecs::ZSTD_inBuffer ib = {in, n, 0};
+            auto room = [&] {
+                if (out.size() - pos < (1u << 16)) out.resize(out.size() * 2);
+            };
+            while (ib.pos < ib.size) {
+                room();
+                codecs::ZSTD_outBuffer ob = {out.data() + pos, out.size() - pos, 0};
+                if (z->isError(z->compressStream(cs, &ob, &ib))) die("write error: zstd");
+                pos += ob.pos;
             }
+            for (size_t left = 1; left;) {
+                room();
+                codecs::ZSTD_outBuffer ob = {out.data() + pos, out.size() - pos, 0};
+                left = z->endStream(cs, &ob);
+                if (z->isError(left)) die("write error: zstd");
+                pos += ob.pos;
+            }
+            z->freeCStream(cs);
+            out.resize(pos);
+        } else if (codec == XZ) {
+            const codecs::Lzma *l = codecs::Lzma::get(nullptr);
+            codecs::lzma_stream ls;
+            std::memset(&ls, 0, sizeof ls);
+            if (!l || l->easy_encoder(&ls, (uint32_t)level, codecs::LZMA_CHECK_CRC64) != codecs::LZMA_OK) die("xz initialisation failed");
+            out.resize(n / 2 + (1 << 16));
+            size_t pos = 0;
+            ls.next_in = (const uint8_t *)in;
+            ls.avail_in = n;
+            int r = codecs::LZMA_OK;
+            while (r == codecs::LZMA_OK) {
+                if (out.size() - pos < (1u << 16)) out.resize(out.size() * 2);
+                ls.next_out = (uint8_t *)out.data() + pos;
+                ls.avail_out = out.size() - pos;
+                r = l->code(&ls, ls.avail_in ? codecs::LZMA_RUN : codecs::LZMA_FINISH);
+                pos = out.size() - ls.avail_out;
+                if (r != codecs::LZMA_OK && r != codecs::LZMA_STREAM_END) die("write error: xz");
+            }
+            l->end(&ls);
+            out.resize(pos);
         } else {
-            raw_write(buf.data(), buf.size());
+            out.assign(in, in + n);
         }
     }
-    bool plain() const { return !gz_ && !zcs_ && !xz_; }
+    // formatted records: compressed here when the output is (callers that compressed the batch themselves use write_raw)
+    void write(const std::vector<char> &buf) {
+        if (buf.empty()) return;
+        if (codec_ == PLAIN) {
+            raw_write(buf.data(), buf.size());
+        } else {
+            compress_member(codec_, level_, buf.data(), buf.size(), cbuf_);
+            write_raw(cbuf_);
+        }
+    }
+    void write_raw(const std::vector<char> &bytes) {
+        if (bytes.empty()) return;
+        wrote_member_ = true;
+        raw_write(bytes.data(), bytes.size());
+    }
     // plain streams only: the pieces of a batch in one gather write per IOV_MAX entries
     void write_gather(std::vector<struct iovec> &iov) {
         const int fd = fileno(f_);
@@ -269,52 +334,25 @@ class Output {
     }
     // the last flush is where a full disk or a closed pipe shows: a failure here must not end in "Retained ..."
     void close() {
-        gzFile gz = gz_;
         FILE *f = f_;
-        gz_ = nullptr;
+        if (!f) return;
+        if (codec_ != PLAIN && !wrote_member_) {  // nothing was kept: still a valid (empty) file of its format
+            compress_member(codec_, level_, "", 0, cbuf_);
+            raw_write(cbuf_.data(), cbuf_.size());
+        }
         f_ = nullptr;
-        if (gz && gzclose(gz) != Z_OK) die("write error");
-        if (f && zcs_) {
-            size_t left = 1;
-            while (left) {
-                codecs::ZSTD_outBuffer out = {cbuf_.data(), cbuf_.size(), 0};
-                left = zstd_->endStream(zcs_, &out);
-                if (zstd_->isError(left)) die("write error: zstd");
-                f_ = f, raw_write(cbuf_.data(), out.pos), f_ = nullptr;
-            }
-            zstd_->freeCStream(zcs_);
-            zcs_ = nullptr;
-        }
-        if (f && xz_) {
-            int r = codecs::LZMA_OK;
-            ls_.avail_in = 0;
-            while (r == codecs::LZMA_OK) {
-                ls_.next_out = (uint8_t *)cbuf_.data();
-                ls_.avail_out = cbuf_.size();
-                r = lzma_->code(&ls_, codecs::LZMA_FINISH);
-                if (r != codecs::LZMA_OK && r != codecs::LZMA_STREAM_END) die("write error: xz");
-                f_ = f, raw_write(cbuf_.data(), cbuf_.size() - ls_.avail_out), f_ = nullptr;
-            }
-            lzma_->end(&ls_);
-            xz_ = false;
-        }
-        if (f) {
-            if (std::fflush(f) != 0) die("write error");
-            if (own_ && std::fclose(f) != 0) die("write error");
-        }
+        if (std::fflush(f) != 0) die("write error");
+        if (own_ && std::fclose(f) != 0) die("write error");
     }
 
   private:
     void raw_write(const char *p, size_t n) {
         if (n && std::fwrite(p, 1, n, f_) != n) die("write error");
     }
-    gzFile gz_ = nullptr;
     FILE *f_ = nullptr;
-    bool own_ = false, xz_ = false;
-    const codecs::Zstd *zstd_ = nullptr;
-    void *zcs_ = nullptr;
-    const codecs::Lzma *lzma_ = nullptr;
-    codecs::lzma_stream ls_;
+    bool own_ = false, wrote_member_ = false;
+    Codec codec_ = PLAIN;
+    int level_ = 0;
     std::vector<char> cbuf_;
 };
 
@@ -356,6 +394,8 @@ struct Batch {
     const char *ext = nullptr;   // ... or the memory-mapped input file they live in (parallel reader)
     const char *chars() const { return ext ? ext : text.data(); }
     std::vector<char> out1, out2;  // formatted kept records (filled by the format stage)
+    std::vector<char> comp1, comp2;  // ... and, for a compressed output, their complete member (same stage)
+    bool compressed = false;
     std::vector<struct iovec> iov1;  // plain single-file output: what to write, in order -- ranges of the mapped input
                                      // (records that already have their output form) and pieces of out1
     std::vector<uint8_t, DefaultInitAllocator<uint8_t>> bases;  // concatenated sequences (what dcn_filter_batch takes)
@@ -384,6 +424,9 @@ struct Batch {
         ext = nullptr;
         out1.clear();
         out2.clear();
+        comp1.clear();
+        comp2.clear();
+        compressed = false;
         iov1.clear();
         keep.clear();
         hits.clear();
@@ -1254,6 +1297,15 @@ int run_filter(const FilterArgs &a) {
         BatchStats st = map_out ? format_batch_mapped(b, a.rename, b.seq_no, mapped_out.at(b.out_off, b.out_bytes), b.out_bytes)
                         : gather_out ? format_batch_gather(b, a.rename, b.seq_no)
                                      : format_batch(b, a.rename, split_mates, b.seq_no /* rename base, set by the GPU stage */);
+        if (!map_out && !gather_out && !out1_holder->plain()) {  // this batch's member(s), compressed on this worker
+            Output::compress_member(out1_holder->codec(), out1_holder->level(), b.out1.data(), b.out1.size(), b.comp1);
+            if (b.out1.empty()) b.comp1.clear();  // (an empty member per empty batch would only grow the file)
+            b.compressed = true;
+        }
+        if (!map_out && out2 && !out2->plain()) {
+            Output::compress_member(out2->codec(), out2->level(), b.out2.data(), b.out2.size(), b.comp2);
+            if (b.out2.empty()) b.comp2.clear();
+        }
         std::lock_guard<std::mutex> l(stats_m);
         tot.total_seqs += st.total_seqs;
         tot.filtered_seqs += st.filtered_seqs;
@@ -1270,8 +1322,12 @@ int run_filter(const FilterArgs &a) {
                 if (gather_out) {
                     out1_holder->write_gather(b->iov1);
                 } else {
-                    out1_holder->write(b->out1);
-                    if (out2) out2->write(b->out2);
+                    if (b->compressed) out1_holder->write_raw(b->comp1);
+                    else out1_holder->write(b->out1);
+                    if (out2) {
+                        if (!out2->plain()) out2->write_raw(b->comp2);
+                        else out2->write(b->out2);
+                    }
                 }
             }
             pool.put(std::move(b));

@@ -99,7 +99,7 @@ try:
         args = [t_ for t_ in toks if not re.match(r"^[A-Z_]+=", t_)]
         for mode, extra in modes:
             env = dict(os.environ, DCN_CLI_TIMING="1", **envs)
-            out = os.path.join(d, "out.fq")
+            out = os.path.join(d, "out.fq" + os.environ.get("DCN_CLI_OUT_EXT", ""))  # ".gz" / ".zst" / ".xz": compressed output
             t = time.perf_counter()
             p = subprocess.run([os.path.join(ROOT, envs.get("DCN_CLI_BIN", BIN)), "filter", idx_path, fq, "-o", out, "-s", os.path.join(d, "s.json"), "-q", *extra, *args],
                                check=True, env=env, capture_output=True, text=True)

@@ -21,8 +21,8 @@ SC2_REV = CASES["C-2"]["units"][0][0]
 SC2B, SC2B_REV = CASES["C-3-fwd"]["units"][0][1], CASES["C-3-rev"]["units"][0][1]
 
 
-def run(*args, stdin=None, check=True):
-    p = subprocess.run([BIN, *map(str, args)], input=stdin, capture_output=True)
+def run(*args, stdin=None, check=True, env=None):
+    p = subprocess.run([BIN, *map(str, args)], input=stdin, capture_output=True, env=env)
     if check:
         assert p.returncode == 0, p.stderr.decode()
     return p
@@ -134,6 +134,20 @@ def test_filter_compressed_outputs_and_inputs(tmp_path):  # filter_tests.rs:131-
         run("filter", idx, tmp_path / "reads.fastq", "-o", out)
         assert out.stat().st_size > 0 and dec(out.read_bytes()) == plain, ext
         assert run("filter", idx, out).stdout == plain, ext  # and read back by this build (format found by content)
+    # compressed outputs are one member / frame / stream per batch, compressed on the formatter threads: many small
+    # batches must still decode to the plain output, and an output with nothing kept is a valid empty file of its format
+    rng = np.random.default_rng(3)
+    many = [(f"r{i}", SEQ1 if i % 3 else "".join("ACGT"[c] for c in rng.integers(0, 4, 120))) for i in range(600)]
+    fastq(tmp_path / "many.fastq", many)
+    env = dict(os.environ, DCN_CLI_CHUNK_MB="1", DCN_CLI_MAX_BATCH_READS="50")
+    plain_many = run("filter", idx, tmp_path / "many.fastq").stdout
+    assert plain_many.count(b"@r") == 400
+    for ext, dec in decoders.items():
+        out = tmp_path / f"many.fastq.{ext}"
+        run("filter", idx, tmp_path / "many.fastq", "-o", out, "-t", "4", env=env)
+        assert dec(out.read_bytes()) == plain_many, ext
+        run("filter", "-d", idx, tmp_path / "reads.fastq", "-o", out)
+        assert out.stat().st_size > 0 and dec(out.read_bytes()) == b"", ext
     for ext, lo, hi in (("gz", 1, 9), ("zst", 1, 22), ("xz", 0, 9)):  # validate_compression_level, local_filter.rs:95-107
         p = run("filter", idx, tmp_path / "reads.fastq", "-o", tmp_path / f"x.{ext}", "--compression-level", hi + 1, check=False)
         assert p.returncode != 0 and b"compression level" in p.stderr, ext

@@ -82,6 +82,12 @@ try:
     rec.tofile(fq)
     del rec, mat, rnd
     size = os.path.getsize(fq)
+    if os.environ.get("DCN_CLI_IN_CODEC"):  # compressed input: "gzip -1" / "zstd -1" style command, e.g. DCN_CLI_IN_CODEC="gzip -1 -k"
+        t = time.perf_counter()
+        subprocess.run(os.environ["DCN_CLI_IN_CODEC"].split() + [fq], check=True)
+        ext = ".gz" if "gzip" in os.environ["DCN_CLI_IN_CODEC"] else ".zst"
+        fq = fq + ext
+        print(f"input compressed to {os.path.getsize(fq)/1e9:.2f} GB in {time.perf_counter()-t:.1f} s", flush=True)
     variants = [v.split() for v in os.environ.get("DCN_CLI_VARIANTS", "").split(";")] or [[]]
     # a variant may name another driver binary (DCN_CLI_BIN=path, relative to the repo): old vs new on the same files
     bins = sorted({t_.split("=", 1)[1] for v in variants for t_ in v if t_.startswith("DCN_CLI_BIN=")} | {BIN})

@@ -261,6 +261,10 @@ def test_multiline_fasta_and_newline_mapping(tmp_path):  # filter_tests.rs:1133-
     q.write_text(">query\nACGTTTAAGGCCAACC\nACACACACACACATT\n")
     out = run("filter", "-a", "1", idx, q).stdout.decode()
     assert ">query" in out and c5["ref"][0] in out
+    assert run("filter", "-a", "1", idx, "-", stdin=q.read_bytes()).stdout.decode() == out  # the stream (chunk) reader
+    many = "".join(f">q{i}\nACGTTTAAGGCCAACC\nACACACACACACATT\n" for i in range(60000)).encode()
+    got = run("filter", "-a", "1", idx, "-", stdin=many, env=dict(os.environ, DCN_CLI_CHUNK_MB="1")).stdout
+    assert got.count(b">q") == 60000 and got == run("filter", "-a", "1", idx, "-", stdin=many, env=dict(os.environ, DCN_CLI_NO_CHUNK_READER="1")).stdout
     ref = tmp_path / "nl.fa"
     ref.write_text(">reference\nAAAAA\nAAAAA\nAAAAA\nAAAAA\n")
     idx2 = tmp_path / "nl.idx"
@@ -505,6 +509,14 @@ def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
         out = run("filter", idx, tmp_path / name, "-t", 6).stdout
         got = [l[1:].rstrip(b"\r").decode() for l in out.split(b"\n")[0::4] if l]
         assert got == want, name
+        # the same bytes as a stream (stdin, gzip file): the chunk reader cuts it into 1 MB pieces of whole records for
+        # the same parser pool, the tail of every piece travelling to the next; the one-thread reader agrees
+        assert run("filter", idx, "-", "-t", 6, stdin=payload).stdout == out, name
+        (tmp_path / (name + ".gz")).write_bytes(gzip.compress(payload, 1))
+        assert run("filter", idx, tmp_path / (name + ".gz"), "-t", 6).stdout == out, name
+        monkeypatch.setenv("DCN_CLI_NO_CHUNK_READER", "1")
+        assert run("filter", idx, "-", "-t", 6, stdin=payload).stdout == out, name
+        monkeypatch.delenv("DCN_CLI_NO_CHUNK_READER")
         # three ways to the same bytes: the shared output mapping (default for a plain file from a plain file: kept
         # records copied to their final place by the formatter threads), the gather writer (pipes / stdout: ranges of
         # the mapped input where a record already has its output form, formatted pieces otherwise, one writev per

@@ -107,7 +107,8 @@ try:
             env = dict(os.environ, DCN_CLI_TIMING="1", **envs)
             out = os.path.join(d, "out.fq" + os.environ.get("DCN_CLI_OUT_EXT", ""))  # ".gz" / ".zst" / ".xz": compressed output
             t = time.perf_counter()
-            p = subprocess.run([os.path.join(ROOT, envs.get("DCN_CLI_BIN", BIN)), "filter", idx_path, fq, "-o", out, "-s", os.path.join(d, "s.json"), "-q", *extra, *args],
+            inputs = [fq, fq] if os.environ.get("DCN_CLI_PAIRED") else [fq]  # paired: the same file as both mates
+            p = subprocess.run([os.path.join(ROOT, envs.get("DCN_CLI_BIN", BIN)), "filter", idx_path, *inputs, "-o", out, "-s", os.path.join(d, "s.json"), "-q", *extra, *args],
                                check=True, env=env, capture_output=True, text=True)
             dt = time.perf_counter() - t
             s = json.load(open(os.path.join(d, "s.json")))

@@ -821,16 +821,77 @@ __attribute__((target("avx2"))) inline size_t line_end_avx2(const char *d, size_
 }
 #endif
 
+// One record of a mapped file: the record starting at d[p] (p < b, not a blank line) -> its Rec, its sequence appended
+// at bases + nb (COPY; a counting pass leaves the bases alone), the position behind it returned.  `shift` is added to
+// the offsets the Rec keeps into the mapping (two mapped files share one base pointer: paired inputs).
+template <bool AVX2, bool COPY>
+inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq, uint8_t *bases, size_t &nb, Rec &r, uint64_t shift) {
+    auto eol = [&](size_t q) {
+#if defined(__x86_64__)
+        if (AVX2) return line_end_avx2(d, b, q);
+#endif
+        return line_end(d, b, q);
+    };
+    auto trim = [&](size_t s0, size_t e) { return (e > s0 && d[e - 1] == '\r') ? e - 1 : e; };
+    const size_t e0 = eol(p);
+    if (d[p] != (fastq ? '@' : '>')) die("Invalid FASTX record start: expected '>' or '@'");
+    r.id_off = shift + p + 1;
+    r.id_len = (uint32_t)(trim(p + 1, e0) - (p + 1));
+    r.seq_off = nb;
+    r.rec_off = 0;
+    r.rec_len = 0;
+    if (fastq) {
+        // (the '+' line of a well-formed record is "+\n": look there before searching)
+        size_t s1 = e0 + 1, e1 = eol(s1), s2 = e1 + 1;
+        size_t e2 = (s2 + 1 < b && d[s2 + 1] == '\n') ? s2 + 1 : eol(s2);
+        size_t s3 = e2 + 1, e3 = eol(s3);
+        if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
+        size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
+        if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
+        if (COPY) std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
+        nb += t1 - s1;
+        r.qual_off = shift + s3;
+        if (t1 == e1 && t3 == e3 && e2 == s2 + 1 && e3 < b && r.id_len == e0 - (p + 1) && e3 + 1 - p < (1ull << 32)) {
+            r.rec_off = shift + p;
+            r.rec_len = (uint32_t)(e3 + 1 - p);
+        }
+        p = e3 + 1;
+    } else {
+        size_t q = e0 + 1, lines = 0, last_e = 0;
+        bool cr = false;
+        while (q < b && d[q] != '>') {
+            size_t e = eol(q);
+            cr = cr || trim(q, e) != e;
+            if (COPY) std::memcpy(bases + nb, d + q, trim(q, e) - q);
+            nb += trim(q, e) - q;
+            q = e + 1;
+            last_e = e;
+            ++lines;
+        }
+        r.qual_off = NO_QUAL;
+        if (lines == 1 && !cr && last_e < b && r.id_len == e0 - (p + 1) && last_e + 1 - p < (1ull << 32)) {
+            r.rec_off = shift + p;
+            r.rec_len = (uint32_t)(last_e + 1 - p);
+        }
+        p = q;
+    }
+    r.seq_len = (uint32_t)(nb - r.seq_off);
+    return p;
+}
+
+inline bool cli_avx2() {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2") && !std::getenv("DCN_CLI_NO_AVX2");
+    return avx2;
+#else
+    return false;
+#endif
+}
+
 // parse the records in [a, b) of the mapped file into batch (ids / qualities stay in the mapping)
 template <bool AVX2>
 void parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
     out.ext = d;
-    auto eol = [&](size_t p) {
-#if defined(__x86_64__)
-        if (AVX2) return line_end_avx2(d, b, p);
-#endif
-        return line_end(d, b, p);
-    };
     // the sequences of a chunk are at most its own size: one allocation, written through a raw pointer (insert() /
     // push_back() per record cost more than the copy itself)
     out.bases.resize((b - a) / (fastq ? 2 : 1) + 64);
@@ -839,54 +900,13 @@ void parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batc
     out.recs.reserve((b - a) / 192 + 16);
     out.offsets.reserve((b - a) / 192 + 17);
     size_t p = a;
-    auto trim = [&](size_t s0, size_t e) { return (e > s0 && d[e - 1] == '\r') ? e - 1 : e; };
     while (p < b) {
-        size_t e0 = eol(p);
-        if (e0 == p) {  // blank line
-            p = e0 + 1;
+        if (d[p] == '\n') {  // blank line
+            ++p;
             continue;
         }
-        if (d[p] != (fastq ? '@' : '>')) die("Invalid FASTX record start: expected '>' or '@'");
         Rec r;
-        r.id_off = p + 1;
-        r.id_len = (uint32_t)(trim(p + 1, e0) - (p + 1));
-        r.seq_off = nb;
-        if (fastq) {
-            // (the '+' line of a well-formed record is "+\n": look there before searching)
-            size_t s1 = e0 + 1, e1 = eol(s1), s2 = e1 + 1;
-            size_t e2 = (s2 + 1 < b && d[s2 + 1] == '\n') ? s2 + 1 : eol(s2);
-            size_t s3 = e2 + 1, e3 = eol(s3);
-            if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
-            size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
-            if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
-            std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
-            nb += t1 - s1;
-            r.qual_off = s3;
-            if (t1 == e1 && t3 == e3 && e2 == s2 + 1 && e3 < b && r.id_len == e0 - (p + 1) && e3 + 1 - p < (1ull << 32)) {
-                r.rec_off = p;
-                r.rec_len = (uint32_t)(e3 + 1 - p);
-            }
-            p = e3 + 1;
-        } else {
-            size_t q = e0 + 1, lines = 0, last_e = 0;
-            bool cr = false;
-            while (q < b && d[q] != '>') {
-                size_t e = eol(q);
-                cr = cr || trim(q, e) != e;
-                std::memcpy(bases + nb, d + q, trim(q, e) - q);
-                nb += trim(q, e) - q;
-                q = e + 1;
-                last_e = e;
-                ++lines;
-            }
-            r.qual_off = NO_QUAL;
-            if (lines == 1 && !cr && last_e < b && r.id_len == e0 - (p + 1) && last_e + 1 - p < (1ull << 32)) {
-                r.rec_off = p;
-                r.rec_len = (uint32_t)(last_e + 1 - p);
-            }
-            p = q;
-        }
-        r.seq_len = (uint32_t)(nb - r.seq_off);
+        p = parse_mapped_record<AVX2, true>(d, p, b, fastq, bases, nb, r, 0);
         out.recs.push_back(r);
         out.offsets.push_back(nb);
     }
@@ -894,11 +914,93 @@ void parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batc
 }
 
 void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
-#if defined(__x86_64__)
-    static const bool avx2 = __builtin_cpu_supports("avx2") && !std::getenv("DCN_CLI_NO_AVX2");
-    if (avx2) return parse_mapped_chunk_impl<true>(d, a, b, fastq, out);
-#endif
+    if (cli_avx2()) return parse_mapped_chunk_impl<true>(d, a, b, fastq, out);
     parse_mapped_chunk_impl<false>(d, a, b, fastq, out);
+}
+
+// ---- two mapped files, mates in step (the parallel form of the paired reader) ------------------------------------------
+// records in [a, b), walked like the parser walks them but without touching the sequences
+size_t count_mapped_records(const char *d, size_t a, size_t b, bool fastq) {
+    size_t n = 0, nb = 0;
+    Rec r;
+    for (size_t p = a; p < b;) {
+        if (d[p] == '\n') {
+            ++p;
+            continue;
+        }
+        p = cli_avx2() ? parse_mapped_record<true, false>(d, p, b, fastq, nullptr, nb, r, 0)
+                       : parse_mapped_record<false, false>(d, p, b, fastq, nullptr, nb, r, 0);
+        ++n;
+    }
+    return n;
+}
+
+// position behind the first `skip` records at or after a (a is a record start or a blank line)
+size_t skip_mapped_records(const char *d, size_t a, size_t size, bool fastq, size_t skip) {
+    size_t nb = 0, p = a;
+    Rec r;
+    while (skip && p < size) {
+        if (d[p] == '\n') {
+            ++p;
+            continue;
+        }
+        p = cli_avx2() ? parse_mapped_record<true, false>(d, p, size, fastq, nullptr, nb, r, 0)
+                       : parse_mapped_record<false, false>(d, p, size, fastq, nullptr, nb, r, 0);
+        --skip;
+    }
+    return p;
+}
+
+// mates of [a1, b1) in file 1 and of [a2, b2) in file 2 (the same number of records), interleaved into one batch
+// (mate 1, mate 2, ...).  Offsets into the mappings are relative to the lower of the two base pointers.
+template <bool AVX2>
+void parse_mapped_pairs_impl(const char *d1, size_t a1, size_t b1, const char *d2, size_t a2, size_t b2, bool fastq, Batch &out) {
+    const char *base = d1 < d2 ? d1 : d2;
+    const uint64_t sh1 = (uint64_t)(d1 - base), sh2 = (uint64_t)(d2 - base);
+    out.ext = base;
+    out.paired = true;
+    out.bases.resize(((b1 - a1) + (b2 - a2)) / (fastq ? 2 : 1) + 128);  // a sequence is at most (half of) its record's bytes
+    uint8_t *bases = out.bases.data();
+    size_t nb = 0;
+    out.recs.reserve((b1 - a1) / 96 + 32);
+    out.offsets.reserve((b1 - a1) / 96 + 33);
+    out.unit_id.reserve((b1 - a1) / 96 + 32);
+    size_t p1 = a1, p2 = a2;
+    uint32_t unit = 0;
+    for (;;) {
+        while (p1 < b1 && d1[p1] == '\n') ++p1;
+        while (p2 < b2 && d2[p2] == '\n') ++p2;
+        if (p1 >= b1 || p2 >= b2) break;
+        Rec r;
+        p1 = parse_mapped_record<AVX2, true>(d1, p1, b1, fastq, bases, nb, r, sh1);
+        out.recs.push_back(r);
+        out.offsets.push_back(nb);
+        p2 = parse_mapped_record<AVX2, true>(d2, p2, b2, fastq, bases, nb, r, sh2);
+        out.recs.push_back(r);
+        out.offsets.push_back(nb);
+        out.unit_id.push_back(unit);
+        out.unit_id.push_back(unit);
+        ++unit;
+    }
+    if (p1 < b1 || p2 < b2) die("internal: the two inputs' chunks do not hold the same number of records");
+    out.bases.resize(nb);
+}
+
+void parse_mapped_pairs(const char *d1, size_t a1, size_t b1, const char *d2, size_t a2, size_t b2, bool fastq, Batch &out) {
+    if (cli_avx2()) return parse_mapped_pairs_impl<true>(d1, a1, b1, d2, a2, b2, fastq, out);
+    parse_mapped_pairs_impl<false>(d1, a1, b1, d2, a2, b2, fastq, out);
+}
+
+// fn(i) for i in [0, n) on `threads` threads
+template <typename F>
+void parallel_for(size_t n, size_t threads, F fn) {
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < std::min(threads, n); ++t)
+        pool.emplace_back([&] {
+            for (size_t i; (i = next.fetch_add(1)) < n;) fn(i);
+        });
+    for (auto &t : pool) t.join();
 }
 
 struct BatchStats {
@@ -1271,15 +1373,19 @@ int run_filter(const FilterArgs &a) {
                      paired_stdin ? "interleaved" : paired ? "paired" : "single", opts.c_str());
     }
     // plain regular single input: mmap + parallel parsing of record-aligned chunks (see stage 1)
-    MappedFile mapped;
+    MappedFile mapped, mapped2;
     bool parallel_in = !paired && a.input != "-" && mapped.open(a.input);
+    // two plain regular files of mates: both mapped, cut at the same record numbers, parsed in parallel as well
+    const bool pair_in = paired && !paired_stdin && a.input != "-" && a.input2 != "-" && !std::getenv("DCN_CLI_NO_PAIR_MMAP") &&
+                         mapped.open(a.input) && mapped2.open(a.input2) && mapped.size > 0 && mapped2.size > 0 &&
+                         (mapped.data[0] == '@' || mapped.data[0] == '>') && mapped.data[0] == mapped2.data[0];
     // ... and if the output is a plain file too, the formatter threads write it through a shared mapping
     MappedOutput mapped_out;
     const bool plain_out = a.output != "-" && !ends_with(a.output, ".gz") && !ends_with(a.output, ".zst") && !ends_with(a.output, ".xz");
     // (one write(2) / writev(2) stream moves 4.8-6.6 GB/s on tmpfs and stalls the stages in front of it: 0.90-0.95 s
     // against 0.68-0.76 s through the mapping for the same 5 GB input, profiles/r02_cli_bench.txt)
-    if (parallel_in && plain_out && !std::getenv("DCN_CLI_NO_MMAP_OUT"))
-        mapped_out.open(a.output, 5 * (uint64_t)mapped.size + (1u << 20));  // >= any formatted size (renamed ids: <= 20 digits)
+    if ((parallel_in || (pair_in && !a.has_output2)) && plain_out && !std::getenv("DCN_CLI_NO_MMAP_OUT"))
+        mapped_out.open(a.output, 5 * ((uint64_t)mapped.size + (pair_in ? mapped2.size : 0)) + (1u << 20));  // >= any formatted size (renamed ids: <= 20 digits)
     const bool map_out = mapped_out.active();
     std::unique_ptr<Output> out1_holder;
     if (!map_out) out1_holder.reset(new Output(a.output, a.compression_level));
@@ -1310,6 +1416,7 @@ int run_filter(const FilterArgs &a) {
     if (parallel_in && mapped.data[0] != '@' && mapped.data[0] != '>') die("Invalid FASTX record start: expected '>' or '@'");
     // one stream that is not a mappable plain file (stdin, gzip / zstd / xz): the chunk reader below
     const bool chunk_in = !paired && !parallel_in && !std::getenv("DCN_CLI_NO_CHUNK_READER");
+    const bool pool_in = parallel_in || chunk_in || pair_in;  // batches come out of the parser pool
     BatchPool pool;
     Queue<std::unique_ptr<Batch>> parsed(4);
     std::unique_ptr<OrderedStage> parse_stage;
@@ -1339,6 +1446,58 @@ int run_filter(const FilterArgs &a) {
                 b->seq_no = end;
                 parse_stage->push(std::move(b));
                 pos = end;
+            }
+            parse_stage->finish();
+        });
+    } else if (pair_in) {
+        const char *d1 = mapped.data, *d2 = mapped2.data;
+        const size_t size1 = mapped.size, size2 = mapped2.size;
+        const bool fq = d1[0] == '@';
+        parse_stage.reset(new OrderedStage(n_workers, 4 * n_workers + 8, [d1, d2, fq, &t_parse](Batch &b) {
+            StageClock::Scope sc(t_parse);
+            // chunk bounds travel in the empty batch: file 1 in offsets[0] / seq_no, file 2 in out_off / out_bytes
+            const size_t a1 = (size_t)b.offsets[0], b1 = (size_t)b.seq_no, a2 = (size_t)b.out_off, b2 = (size_t)b.out_bytes;
+            b.offsets.assign(1, 0);
+            b.out_off = b.out_bytes = 0;
+            parse_mapped_pairs(d1, a1, b1, d2, a2, b2, fq, b);
+        }));
+        reader = std::thread([&, d1, d2, size1, size2, fq] {
+            // Mates sit at the same record NUMBER of their files, not at the same byte: both files are cut into chunks at
+            // record boundaries and the chunks' records counted (a walk without the sequence copies, all workers), which
+            // gives every cut of file 1 a record number; the byte in file 2 behind that many records is found by walking
+            // from the nearest cut of file 2 (again on all workers).  The pairs of ranges then go to the parser pool.
+            size_t chunk_cap = 12u << 20;
+            if (const char *e = std::getenv("DCN_CLI_CHUNK_MB")) chunk_cap = (size_t)std::max(1, std::atoi(e)) << 20;  // tuning hook
+            auto cuts_of = [&](const char *d, size_t size) {
+                const size_t chunk = std::min<size_t>(std::max<size_t>(size / (4 * n_workers), 2u << 20), chunk_cap);
+                std::vector<size_t> cuts{0};
+                while (cuts.back() < size) cuts.push_back(cuts.back() + chunk >= size ? size : next_record_start(d, size, cuts.back() + chunk, fq));
+                return cuts;
+            };
+            const std::vector<size_t> c1 = cuts_of(d1, size1), c2 = cuts_of(d2, size2);
+            std::vector<size_t> n1(c1.size(), 0), n2(c2.size(), 0);  // records before each cut
+            parallel_for(c1.size() - 1 + c2.size() - 1, n_workers, [&](size_t i) {
+                if (i < c1.size() - 1) n1[i + 1] = count_mapped_records(d1, c1[i], c1[i + 1], fq);
+                else n2[i - (c1.size() - 1) + 1] = count_mapped_records(d2, c2[i - (c1.size() - 1)], c2[i - (c1.size() - 1) + 1], fq);
+            });
+            for (size_t i = 1; i < n1.size(); ++i) n1[i] += n1[i - 1];
+            for (size_t i = 1; i < n2.size(); ++i) n2[i] += n2[i - 1];
+            if (n1.back() > n2.back()) die("Paired input ended with an unpaired record");
+            if (n1.back() < n2.back()) die("Second input has more records than the first");
+            std::vector<size_t> at2(c1.size(), 0);  // byte of file 2 behind n1[j] records
+            at2.back() = size2;
+            parallel_for(c1.size() - 1, n_workers, [&](size_t j) {
+                if (j == 0) return;
+                const size_t k = (size_t)(std::upper_bound(n2.begin(), n2.end(), n1[j]) - n2.begin()) - 1;  // n2[k] <= n1[j]
+                at2[j] = skip_mapped_records(d2, c2[k], size2, fq, n1[j] - n2[k]);
+            });
+            for (size_t j = 0; j + 1 < c1.size(); ++j) {
+                std::unique_ptr<Batch> b = pool.get();
+                b->offsets[0] = c1[j];  // see the worker lambda
+                b->seq_no = c1[j + 1];
+                b->out_off = at2[j];
+                b->out_bytes = at2[j + 1];
+                parse_stage->push(std::move(b));
             }
             parse_stage->finish();
         });
@@ -1423,7 +1582,7 @@ int run_filter(const FilterArgs &a) {
             parsed.finish();
         });
     }
-    auto next_parsed = [&](std::unique_ptr<Batch> &b) { return (parallel_in || chunk_in) ? parse_stage->pop(b) : parsed.pop(b); };
+    auto next_parsed = [&](std::unique_ptr<Batch> &b) { return pool_in ? parse_stage->pop(b) : parsed.pop(b); };
 
     // The parsers are already running: HIP start-up (~0.25 s) and the index load happen behind them.
     std::unique_ptr<deacon::Index> index_holder;
@@ -1444,7 +1603,7 @@ int run_filter(const FilterArgs &a) {
     std::vector<BatchStats> stats_by_batch;
     std::mutex stats_m;
     BatchStats tot;
-    OrderedStage format_stage((parallel_in || chunk_in) ? n_workers : 2, 2 * n_workers + 2, [&](Batch &b) {
+    OrderedStage format_stage(pool_in ? n_workers : 2, 2 * n_workers + 2, [&](Batch &b) {
         StageClock::Scope sc(t_format);
         BatchStats st = map_out ? format_batch_mapped(b, a.rename, b.seq_no, mapped_out.at(b.out_off, b.out_bytes), b.out_bytes)
                         : gather_out ? format_batch_gather(b, a.rename, b.seq_no)

@@ -543,3 +543,46 @@ def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
     # nothing kept: an empty file, not the reservation
     run("filter", idx, tmp_path / "in.fa", "-a", 60000, "-o", tmp_path / "none.fa")
     assert (tmp_path / "none.fa").stat().st_size == 0
+
+
+@gpu
+def test_paired_files_in_parallel_match_the_record_reader(tmp_path, monkeypatch):
+    """two plain files of mates are cut at the same record NUMBERS (their bytes differ: ids of different lengths,
+    mate 2 longer than mate 1, CRLF in one file, a blank line here and there) and parsed on the worker pool; the
+    record-by-record reader (DCN_CLI_NO_PAIR_MMAP) must give the same bytes for every output form"""
+    rng = np.random.default_rng(77)
+    genome = random_reads(rng, 1, 40_000, 40_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    n = 30_000
+    l1, l2 = [], []
+    for i in range(n):
+        a, b = int(rng.integers(40, 100)), int(rng.integers(60, 160))
+        s = int(rng.integers(0, len(genome) - 200))
+        m1 = genome[s:s + a] if i % 2 else random_reads(rng, 1, a, a)[0]
+        m2 = genome[s + 20:s + 20 + b] if i % 2 else random_reads(rng, 1, b, b)[0]
+        l1.append(b"@p%d/1\n%s\n+\n%s\n" % (i, m1, b"I" * a) + (b"\n" if i % 5000 == 7 else b""))
+        l2.append(b"@pair-%d/2 extra\n%s\n+\n%s\n" % (i, m2, b"@" * b))
+    r1, r2 = tmp_path / "r1.fq", tmp_path / "r2.fq"
+    r1.write_bytes(b"".join(l1))
+    r2.write_bytes(b"".join(l2).replace(b"\n", b"\r\n"))
+    monkeypatch.setenv("DCN_CLI_CHUNK_MB", "1")
+    for extra in ([], ["-d"], ["-R"], ["-a", "1", "-r", "0.0"]):
+        outs = {}
+        for mode in ("pool", "reader"):
+            if mode == "reader":
+                monkeypatch.setenv("DCN_CLI_NO_PAIR_MMAP", "1")
+            outs[mode] = [run("filter", idx, r1, r2, "-t", 5, *extra).stdout]
+            run("filter", idx, r1, r2, "-t", 5, "-o", tmp_path / f"{mode}.fq", *extra)
+            outs[mode].append((tmp_path / f"{mode}.fq").read_bytes())
+            run("filter", idx, r1, r2, "-t", 5, "-o", tmp_path / f"{mode}1.fq", "-O", tmp_path / f"{mode}2.fq", *extra)
+            outs[mode] += [(tmp_path / f"{mode}1.fq").read_bytes(), (tmp_path / f"{mode}2.fq").read_bytes()]
+            monkeypatch.delenv("DCN_CLI_NO_PAIR_MMAP", raising=False)
+        assert outs["pool"] == outs["reader"], extra
+        assert outs["pool"][0] == outs["pool"][1] and (extra == ["-d"] or len(outs["pool"][0]) > 100_000)
+    # a file of mates that ends early, or runs on, is an error either way
+    r2.write_bytes(b"".join(l2[:-3]))
+    p = run("filter", idx, r1, r2, check=False)
+    assert p.returncode != 0 and b"unpaired" in p.stderr
+    r2.write_bytes(b"".join(l2 + l2[:2]))
+    p = run("filter", idx, r1, r2, check=False)
+    assert p.returncode != 0 and b"more records" in p.stderr

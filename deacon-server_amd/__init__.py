@@ -5,9 +5,9 @@ from . import _native, client, distributed, server
 from ._native import DeaconHipError, build, declared_symbols
 from .filter import (DEFAULT_KMER_LENGTH, DEFAULT_WINDOW_SIZE, FilterProcessor, Index, PendingBatch, PinnedBuffer,
                      concat_reads, get_minimizer_hashes_and_positions, pack_ascii, paired_should_keep,
-                     stats_allreduce, unpaired_should_keep)
+                     get_minimizer_variant, set_minimizer_variant, stats_allreduce, unpaired_should_keep)
 
 __all__ = ["DeaconHipError", "build", "declared_symbols", "Index", "FilterProcessor", "PinnedBuffer", "PendingBatch", "concat_reads",
-           "pack_ascii", "stats_allreduce",
+           "pack_ascii", "stats_allreduce", "set_minimizer_variant", "get_minimizer_variant",
            "get_minimizer_hashes_and_positions", "unpaired_should_keep", "paired_should_keep",
            "DEFAULT_KMER_LENGTH", "DEFAULT_WINDOW_SIZE"]

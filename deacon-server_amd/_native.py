@@ -66,6 +66,8 @@ _SIGNATURES = {
     "dcn_version": (C.c_char_p, []),
     "dcn_last_error": (C.c_char_p, []),
     "dcn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "dcn_set_minimizer_variant": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "dcn_get_minimizer_variant": (C.c_int, [_u32p, _u32p, _u32p]),
     "dcn_index_from_keys": (C.c_int, [_vp, C.c_uint64, C.c_uint8, C.c_uint8, C.c_int, C.POINTER(_vp)]),
     "dcn_index_from_file": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_vp)]),
     "dcn_index_build": (C.c_int, [_vp, _vp, C.c_uint32, C.c_uint8, C.c_uint8, C.c_float, C.c_uint64, C.c_int,

@@ -163,6 +163,10 @@ struct dcn_scan_args {
     uint8_t *dump_valid;
     uint32_t *dump_count; // per tile
     uint32_t dump_abs;    // 1: dump_pos holds the low 32 bits of the absolute base index instead of the read position
+    // parity-pinning variant (scan_kernel<..., VAR>; filled in by dcn_launch_scan from dcn_set_minimizer_variant)
+    uint32_t nt_rot;         // ntHash rotation per base (1)
+    uint32_t cmp_mask;       // hash bits that are compared (0xFFFF0000)
+    uint32_t nt_combine_xor; // 0: fw + rc, 1: fw ^ rc
 };
 
 // ---- kernels launched by api.hip -------------------------------------------------------------------

@@ -26,6 +26,8 @@
 #include "dcn_internal.h"
 #include "dcn_probe.h"
 
+#include <atomic>
+
 namespace {
 
 // classic ntHash seeds (low 32 bits, listed A,C,G,T) indexed by the 2-bit code A=0 C=1 T=2 G=3,
@@ -121,10 +123,15 @@ struct IntTag {
 // W > 0: window size known at compile time, ring in registers.  W == 0: runtime w, ring in dynamic LDS.
 // FAST: the decisions-only instantiation (a.early_out_max_items != 0), kept apart so that the counting kernel's
 // register allocation does not carry the early-out path
-template <int W, bool K128, bool DUMP, bool FAST>
+// VAR: the parity-pinning variant (dcn_set_minimizer_variant): ntHash rotation per base, number of
+// hash bits compared and the fw/rc combination are run-time values and the window keys are 64 bits wide (hash bits
+// above, position below).  Only instantiated for W == 0; the default rules never take it, so the kernels above are
+// the same code with or without it.
+template <int W, bool K128, bool DUMP, bool FAST, bool VAR = false>
 __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES) void scan_kernel(dcn_scan_args a) {
+    static_assert(!VAR || (W == 0 && !FAST), "the variant path is the generic-w counting / dump kernel");
     __shared__ WaveShared sh;
-    extern __shared__ uint2 dyn_ring[]; // only for W == 0: [w][64] (lkey, rkey)
+    extern __shared__ __align__(16) uint2 dyn_ring[]; // only for W == 0: [w][64] (lkey, rkey); VAR: [w][64] of two u64 keys
 
     const int lane = threadIdx.x;
     const uint32_t NT = *a.n_tiles;
@@ -171,13 +178,15 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
         }
         sh.local[uslot] = loc ? 1 : 0;
     }
+    const uint32_t ROT = VAR ? a.nt_rot : 1u;          // ntHash rotation per base
+    const uint32_t ROTR = (32u - ROT) & 31u;           // the reverse strand rotates the other way
     if (lane < 16) {
         uint32_t in = lane & 3, out = lane >> 2;
         uint4 e;
         e.x = NT_F[in];
-        e.y = rotl32(NT_F[in ^ 2], (k - 1) & 31);
-        e.z = rotl32(NT_F[out], k & 31);  // rotl(F[out], k-1), pre-rotated by the next step's rotl 1
-        e.w = rotl32(NT_F[out ^ 2], 31);  // F[out^2], pre-rotated by the next step's rotr 1
+        e.y = rotl32(NT_F[in ^ 2], (ROT * (k - 1)) & 31);
+        e.z = rotl32(NT_F[out], (ROT * k) & 31);  // rotl(F[out], ROT*(k-1)), pre-rotated by the next step's rotl ROT
+        e.w = rotl32(NT_F[out ^ 2], ROTR);        // F[out^2], pre-rotated by the next step's rotr ROT
         sh.tab[lane] = e;
     }
     __syncthreads();
@@ -197,8 +206,8 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             if ((tt & 15) == 0) cur = __funnelshift_r(packed[q_in + (tt >> 4)], packed[q_in + (tt >> 4) + 1], sh_in);
             uint32_t c = (cur >> (2 * (tt & 15))) & 3;
             uint4 e = sh.tab[c];
-            fw = rotl32(fw, 1) ^ e.x;
-            rc = rotl32(rc, 31) ^ e.y;
+            fw = rotl32(fw, VAR ? ROT : 1u) ^ e.x;
+            rc = rotl32(rc, VAR ? ROTR : 31u) ^ e.y;
             tg += c >> 1;
         }
     }
@@ -548,6 +557,9 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             ringL[r] = 0xFFFFFFFFu;
             ringR[r] = 0;
         }
+    } else if (VAR) {
+        for (uint32_t r = 0; r < w; ++r)
+            reinterpret_cast<ulonglong2 *>(dyn_ring)[r * DCN_WAVE + lane] = make_ulonglong2(~0ull, 0ull);
     } else {
         for (uint32_t r = 0; r < w; ++r) dyn_ring[r * DCN_WAVE + lane] = make_uint2(0xFFFFFFFFu, 0u);
     }
@@ -625,11 +637,11 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             const uint32_t hi_in = (w_in >> (2 * r + 1)) & 1;
             const uint32_t hl = (w_l >> (2 * r + 1)) & 1;
             // (v_bitop3_b32, one instruction each: a ^ b ^ c = table 0x96; (a & b) | c = 0xEA; (~a & b) | c = 0xAE)
-            fw = __builtin_amdgcn_bitop3_b32(rotl32(fw, 1), zprev, e.x, 0x96);
-            rc = __builtin_amdgcn_bitop3_b32(rotl32(rc, 31), wprev, e.y, 0x96);
+            fw = __builtin_amdgcn_bitop3_b32(rotl32(fw, VAR ? ROT : 1u), zprev, e.x, 0x96);
+            rc = __builtin_amdgcn_bitop3_b32(rotl32(rc, VAR ? ROTR : 31u), wprev, e.y, 0x96);
             zprev = e.z;
             wprev = e.w;
-            const uint32_t h = fw + rc;
+            const uint32_t h = (VAR && a.nt_combine_xor) ? (fw ^ rc) : (fw + rc);
             const uint32_t jlow = j & 0xFFFFu;
             const uint32_t lk = __builtin_amdgcn_bitop3_b32(h, keymask, jlow, 0xEA);
             const uint32_t rk = __builtin_amdgcn_bitop3_b32(h, keymask, jlow, 0xAE);
@@ -654,6 +666,21 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     lmin = min(pl, ringL[(r + 1) % STEP]);
                     rmax = max(pr, ringR[(r + 1) % STEP]);
                 }
+            } else if constexpr (VAR) {
+                // variant rules: a.cmp_mask selects the hash bits that are compared (top 16, or all 32); ties still go
+                // to the leftmost / rightmost k-mer, so the position sits below the hash bits of a 64-bit key
+                ulonglong2 *ring64 = reinterpret_cast<ulonglong2 *>(dyn_ring);
+                ring64[gslot * DCN_WAVE + lane] = make_ulonglong2(((unsigned long long)(h & a.cmp_mask) << 32) | j,
+                                                                  ((unsigned long long)(~h & a.cmp_mask) << 32) | j);
+                gslot = gslot + 1 == w ? 0 : gslot + 1;
+                unsigned long long lmin64 = ~0ull, rmax64 = 0ull;
+                for (uint32_t qq = 0; qq < w; ++qq) {
+                    ulonglong2 v = ring64[qq * DCN_WAVE + lane];
+                    lmin64 = v.x < lmin64 ? v.x : lmin64;
+                    rmax64 = v.y > rmax64 ? v.y : rmax64;
+                }
+                lmin = (uint32_t)lmin64;
+                rmax = (uint32_t)rmax64;
             } else {
                 // generic w: ring of w keys per lane in LDS, O(w) rescan per step
                 dyn_ring[gslot * DCN_WAVE + lane] = make_uint2(lk, rk);
@@ -885,11 +912,11 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     }
 }
 
-template <int W>
+template <int W, bool VAR = false>
 int launch_w(const dcn_scan_args &args, uint32_t blocks, bool dump, bool k128, size_t dyn, hipStream_t stream) {
 #define DCN_LAUNCH(K128_, DUMP_, FAST_)                                                               \
     do {                                                                                              \
-        auto kern = scan_kernel<W, K128_, DUMP_, FAST_>;                                              \
+        auto kern = scan_kernel<W, K128_, DUMP_, FAST_ && !VAR, VAR>;                                 \
         if (dyn > 0) {                                                                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
@@ -914,10 +941,44 @@ int launch_w(const dcn_scan_args &args, uint32_t blocks, bool dump, bool k128, s
 
 } // namespace
 
-int dcn_launch_scan(const dcn_scan_args &args, uint32_t max_tiles, bool dump, hipStream_t stream) {
+// ---- the parity-pinning variant (process-wide) ---------------------------------------------------
+namespace {
+std::atomic<uint32_t> g_variant{(1u << 16) | (16u << 8) | 0u}; // rot << 16 | cmp_bits << 8 | combine
+}
+
+int dcn_set_minimizer_variant(uint32_t nt_rot, uint32_t cmp_bits, uint32_t combine) {
+    if (nt_rot < 1 || nt_rot > 31) return dcn_fail(DCN_ERR_ARG, "minimizer variant: rotation must be 1..31");
+    if (cmp_bits != 16 && cmp_bits != 32) return dcn_fail(DCN_ERR_ARG, "minimizer variant: 16 or 32 hash bits are compared");
+    if (combine > 1) return dcn_fail(DCN_ERR_ARG, "minimizer variant: combine is 0 (fw + rc) or 1 (fw ^ rc)");
+    g_variant.store((nt_rot << 16) | (cmp_bits << 8) | combine);
+    return DCN_OK;
+}
+
+int dcn_get_minimizer_variant(uint32_t *nt_rot, uint32_t *cmp_bits, uint32_t *combine) {
+    const uint32_t v = g_variant.load();
+    if (nt_rot) *nt_rot = v >> 16;
+    if (cmp_bits) *cmp_bits = (v >> 8) & 0xFF;
+    if (combine) *combine = v & 0xFF;
+    return DCN_OK;
+}
+
+int dcn_launch_scan(const dcn_scan_args &args_in, uint32_t max_tiles, bool dump, hipStream_t stream) {
     if (max_tiles == 0) return DCN_OK;
     uint32_t blocks = (max_tiles + DCN_WAVE - 1) / DCN_WAVE;
-    bool k128 = args.k > 32;
+    bool k128 = args_in.k > 32;
+    const uint32_t v = g_variant.load();
+    if (v != ((1u << 16) | (16u << 8) | 0u)) {
+        // not the rules of SURVEY.md 8a row A4: one generic kernel with the three choices as run-time values
+        dcn_scan_args args = args_in;
+        args.nt_rot = v >> 16;
+        args.cmp_mask = ((v >> 8) & 0xFF) == 32 ? 0xFFFFFFFFu : 0xFFFF0000u;
+        args.nt_combine_xor = v & 0xFF;
+        args.early_out_max_items = 0;
+        if (args.w > 128) return dcn_fail(DCN_ERR_ARG, "minimizer variant: w <= 128 (two u64 keys per window slot in LDS)");
+        size_t dyn = (size_t)args.w * DCN_WAVE * sizeof(ulonglong2);
+        return launch_w<0, true>(args, blocks, dump, k128, dyn, stream);
+    }
+    const dcn_scan_args &args = args_in;
     switch (args.w) {
     case 15: return launch_w<15>(args, blocks, dump, k128, 0, stream);
     case 11: return launch_w<11>(args, blocks, dump, k128, 0, stream);

@@ -59,6 +59,19 @@ def pack_ascii(bases):
     return packed[:2 * g], mask[:g]
 
 
+def set_minimizer_variant(nt_rot=1, cmp_bits=16, combine="add"):
+    """Process-wide parity-pinning switch (include/deacon_hip.h): ntHash rotation per base, hash bits the window
+    minimum compares, and how the strands' hashes are combined ("add" | "xor").  (1, 16, "add") are the rules of
+    SURVEY.md 8a row A4; set it before any index is built or loaded."""
+    N.check(N.lib().dcn_set_minimizer_variant(int(nt_rot), int(cmp_bits), {"add": 0, "xor": 1}[combine]))
+
+
+def get_minimizer_variant():
+    r, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    N.check(N.lib().dcn_get_minimizer_variant(C.byref(r), C.byref(b), C.byref(c)))
+    return r.value, b.value, ("add", "xor")[c.value]
+
+
 class PendingBatch:
     """A batch in flight (dcn_filter_batch_submit): holds the arrays the library reads and writes until wait()."""
 

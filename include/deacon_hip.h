@@ -67,6 +67,19 @@ const char *dcn_version(void);
 const char *dcn_last_error(void);
 int dcn_device_count(int *count);
 
+/* ---- parity-pinning switch ------------------------------------------------------------------------------
+ * The minimizer rule itself lives in a crate the reference only calls: simd_minimizers::canonical_minimizer_positions
+ * (src/filter_common.rs:261-267, src/minimizers.rs:143-148; simd-minimizers 1.3.0 in Cargo.lock:1954-1957).  Three
+ * of its details could not be executed where this library was written ("Notes on A4"): the ntHash
+ * rotation per base (1, or 7 as in the crate's later line), how many hash bits the window minimum compares (the top
+ * 16, or all 32) and how the two strands' hashes are combined (wrapping add, or xor).  The defaults are (1, 16, 0).
+ * Process-wide; set it before the first index is built or loaded -- an index and the reads filtered against it must
+ * use the same rule.  Any other setting runs a generic kernel (slower, counting mode only); tests/golden/
+ * dump_crate_vectors prints vectors from the real crates, and tests/test_crate_vectors.py names the setting that
+ * reproduces them. */
+int dcn_set_minimizer_variant(uint32_t nt_rot, uint32_t cmp_bits, uint32_t combine /* 0: fw + rc, 1: fw ^ rc */);
+int dcn_get_minimizer_variant(uint32_t *nt_rot, uint32_t *cmp_bits, uint32_t *combine);
+
 /* ---- index: replaces index::load_minimizer_hashes (src/index.rs:80-107) ----------------------------- */
 
 /* Build the device set from `n` host u64 minimizer hashes (duplicates allowed; they are merged, as by

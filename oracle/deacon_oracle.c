@@ -107,6 +107,22 @@ static inline int is_acgt(uint8_t c) {
  * ---------------------------------------------------------------------------------------- */
 static const uint32_t NT_F[4] = {0x95c60474u, 0x62a02b4cu, 0x82572324u, 0x4be24456u};
 
+/* The three details of A4 that the constraint suite cannot separate ("Notes on A4"), as run-time
+ * switches so that a run of the real crates (tests/golden/dump_crate_vectors) can be matched without a rewrite:
+ * rotation per base (1 | 7), hash bits compared by the window minimum (16 | 32), fw/rc combination (+ | ^).
+ * Defaults = the rules stated above.  The product has the same switch (dcn_set_minimizer_variant). */
+static uint32_t g_nt_rot = 1, g_cmp_mask = 0xFFFF0000u, g_combine_xor = 0;
+
+int dor_set_variant(uint32_t nt_rot, uint32_t cmp_bits, uint32_t combine_xor) {
+    if (nt_rot < 1 || nt_rot > 31 || (cmp_bits != 16 && cmp_bits != 32) || combine_xor > 1) return DOR_ERR_ARG;
+    g_nt_rot = nt_rot;
+    g_cmp_mask = cmp_bits == 32 ? 0xFFFFFFFFu : 0xFFFF0000u;
+    g_combine_xor = combine_xor;
+    return DOR_OK;
+}
+
+static inline uint32_t nt_combine(uint32_t fw, uint32_t rc) { return g_combine_xor ? (fw ^ rc) : (fw + rc); }
+
 static inline uint32_t rotl32(uint32_t x, unsigned r) {
     r &= 31u;
     return r ? (x << r) | (x >> (32 - r)) : x;
@@ -126,10 +142,10 @@ int64_t dor_canonical_minimizer_positions_naive(const uint8_t *codes, uint64_t n
         uint32_t fw = 0, rc = 0;
         for (uint32_t i = 0; i < k; ++i) {
             uint32_t c = codes[j + i];
-            fw ^= rotl32(NT_F[c], k - 1 - i);
-            rc ^= rotl32(NT_F[c ^ 2u], i);
+            fw ^= rotl32(NT_F[c], g_nt_rot * (k - 1 - i));
+            rc ^= rotl32(NT_F[c ^ 2u], g_nt_rot * i);
         }
-        h[j] = fw + rc;
+        h[j] = nt_combine(fw, rc) & g_cmp_mask;
     }
     uint64_t cnt = 0;
     int have_prev = 0;
@@ -139,9 +155,9 @@ int64_t dor_canonical_minimizer_positions_naive(const uint8_t *codes, uint64_t n
         for (uint64_t t = i; t < i + l; ++t) tg += (codes[t] >> 1) & 1u;
         int canonical = 2 * tg > l;
         uint64_t best = i;
-        uint32_t bh = h[i] >> 16;
+        uint32_t bh = h[i];
         for (uint64_t j = i + 1; j < i + w; ++j) {
-            uint32_t hj = h[j] >> 16;
+            uint32_t hj = h[j];
             if (canonical ? (hj < bh) : (hj <= bh)) {
                 bh = hj;
                 best = j;
@@ -170,25 +186,26 @@ int64_t dor_canonical_minimizer_positions(const uint8_t *codes, uint64_t n, uint
     if ((l & 1) == 0) return DOR_ERR_ARG;
     if (n < l) return 0;
     uint64_t nk = n - k + 1;
-    uint16_t *h = (uint16_t *)malloc(nk * sizeof(uint16_t)); /* only the top 16 bits matter */
+    uint32_t *h = (uint32_t *)malloc(nk * sizeof(uint32_t)); /* only the compared bits are kept */
     if (!h) return DOR_ERR_NOMEM;
+    const uint32_t R = g_nt_rot;
     uint32_t f_rot[4], c_tab[4], c_rot[4];
     for (int c = 0; c < 4; ++c) {
-        f_rot[c] = rotl32(NT_F[c], k - 1);
+        f_rot[c] = rotl32(NT_F[c], R * (k - 1));
         c_tab[c] = NT_F[c ^ 2];
-        c_rot[c] = rotl32(NT_F[c ^ 2], k - 1);
+        c_rot[c] = rotl32(NT_F[c ^ 2], R * (k - 1));
     }
     uint32_t fw = 0, rc = 0;
     for (uint32_t i = 0; i + 1 < k; ++i) {
         uint32_t c = codes[i];
-        fw = rotl32(fw, 1) ^ NT_F[c];
-        rc = rotl32(rc, 31) ^ c_rot[c];
+        fw = rotl32(fw, R) ^ NT_F[c];
+        rc = rotl32(rc, 32 - R) ^ c_rot[c];
     }
     for (uint64_t j = 0; j < nk; ++j) {
         uint32_t a = codes[j + k - 1], r = codes[j];
-        uint32_t fw_out = rotl32(fw, 1) ^ NT_F[a];
-        uint32_t rc_out = rotl32(rc, 31) ^ c_rot[a];
-        h[j] = (uint16_t)((fw_out + rc_out) >> 16);
+        uint32_t fw_out = rotl32(fw, R) ^ NT_F[a];
+        uint32_t rc_out = rotl32(rc, 32 - R) ^ c_rot[a];
+        h[j] = nt_combine(fw_out, rc_out) & g_cmp_mask;
         fw = fw_out ^ f_rot[r];
         rc = rc_out ^ c_tab[r];
     }
@@ -870,5 +887,302 @@ int dor_index_add_sequence(dor_set *set, const uint8_t *seq, uint64_t len, uint3
     }
     int rc = dor_set_insert_many(set, h, (uint64_t)n);
     free(h);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * "port-tuned": the same arithmetic as dor_filter_batch (A1-A8, default A4 rules only), written the
+ * way a CPU implementation that cares about speed would be -- bench.py's second CPU leg, checked
+ * equal to the plain port on its sample before its time is reported.  Differences are purely
+ * mechanical: one workspace per thread (no malloc per read), window minima by the prefix/suffix
+ * ("two-stack") scheme over blocks of w keys instead of a rescan, rolling forward / reverse-
+ * complement k-mer values, a seen-set with epoch tags instead of a fresh set per unit, and units
+ * handed to threads in chunks from a shared cursor.  Still a restatement of
+ * src/filter_common.rs:211-310 + :129-198 + :84-112, not of the crates' SIMD code.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct tuned_ws {
+    uint64_t cap_bases;
+    uint8_t *codes;
+    int64_t *lastbad;       /* index of the last non-ACGT byte at or before i (-1: none) */
+    uint64_t *keyl, *keyr;  /* per k-mer: (compared hash bits << 32 | pos), and its complement form */
+    uint64_t *sufl, *sufr;  /* suffix min / max inside blocks of w */
+    uint64_t *kf, *kr;      /* rolling forward / reverse-complement k-mer values (k <= 32) */
+    uint64_t *hashes;
+    uint64_t cap_hashes, n_hashes;
+    uint64_t *seen_key;     /* epoch-tagged seen-set */
+    uint32_t *seen_tag;
+    uint64_t seen_mask;
+    uint32_t epoch;
+} tuned_ws;
+
+static int tuned_reserve(tuned_ws *ws, uint64_t n) {
+    if (n <= ws->cap_bases) return DOR_OK;
+    uint64_t cap = ws->cap_bases ? ws->cap_bases : 1024;
+    while (cap < n) cap *= 2;
+    free(ws->codes); free(ws->lastbad); free(ws->keyl); free(ws->keyr); free(ws->sufl); free(ws->sufr);
+    free(ws->kf); free(ws->kr);
+    ws->codes = (uint8_t *)malloc(cap);
+    ws->lastbad = (int64_t *)malloc(cap * sizeof(int64_t));
+    ws->keyl = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    ws->keyr = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    ws->sufl = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    ws->sufr = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    ws->kf = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    ws->kr = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    ws->cap_bases = cap;
+    if (!ws->codes || !ws->lastbad || !ws->keyl || !ws->keyr || !ws->sufl || !ws->sufr || !ws->kf || !ws->kr)
+        return DOR_ERR_NOMEM;
+    return DOR_OK;
+}
+
+static int tuned_reserve_hashes(tuned_ws *ws, uint64_t n) {
+    if (n <= ws->cap_hashes) return DOR_OK;
+    uint64_t cap = ws->cap_hashes ? ws->cap_hashes : 1024;
+    while (cap < n) cap *= 2;
+    uint64_t *nh = (uint64_t *)realloc(ws->hashes, cap * sizeof(uint64_t));
+    if (!nh) return DOR_ERR_NOMEM;
+    ws->hashes = nh;
+    ws->cap_hashes = cap;
+    return DOR_OK;
+}
+
+static void tuned_free(tuned_ws *ws) {
+    free(ws->codes); free(ws->lastbad); free(ws->keyl); free(ws->keyr); free(ws->sufl); free(ws->sufr);
+    free(ws->kf); free(ws->kr); free(ws->hashes); free(ws->seen_key); free(ws->seen_tag);
+}
+
+/* appends the valid minimizer hashes of one read to ws->hashes (A1-A6) */
+static int tuned_read_hashes(tuned_ws *ws, const uint8_t *seq, uint64_t len, const dor_params *p) {
+    const uint32_t k = p->k, w = p->w;
+    if (len < k) return DOR_OK;
+    uint64_t n = len;
+    if (p->prefix_length > 0 && len > p->prefix_length) n = p->prefix_length;
+    if (n > 0 && seq[n - 1] == '\n') n -= 1;
+    const uint64_t l = (uint64_t)k + w - 1;
+    if (n < l) return DOR_OK;
+    int rc0 = tuned_reserve(ws, n + w);
+    if (rc0 != DOR_OK) return rc0;
+    const uint64_t nk = n - k + 1, nw = n - l + 1;
+    rc0 = tuned_reserve_hashes(ws, ws->n_hashes + nw);
+    if (rc0 != DOR_OK) return rc0;
+    uint8_t *codes = ws->codes;
+    int64_t last = -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint8_t c = seq[i];
+        codes[i] = (uint8_t)((c >> 1) & 3u);
+        if (!is_acgt(c)) last = (int64_t)i;
+        ws->lastbad[i] = last;
+    }
+    /* rolling ntHash32 + rolling k-mer values */
+    uint32_t f_rot[4], c_tab[4], c_rot[4];
+    for (int c = 0; c < 4; ++c) {
+        f_rot[c] = rotl32(NT_F[c], k - 1);
+        c_tab[c] = NT_F[c ^ 2];
+        c_rot[c] = rotl32(NT_F[c ^ 2], k - 1);
+    }
+    const int small_k = k <= 32;
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    uint32_t fw = 0, rc = 0;
+    uint64_t vf = 0, vr = 0;
+    for (uint32_t i = 0; i + 1 < k; ++i) {
+        uint32_t c = codes[i];
+        fw = rotl32(fw, 1) ^ NT_F[c];
+        rc = rotl32(rc, 31) ^ c_rot[c];
+        if (small_k) {
+            vf |= (uint64_t)c << (2 * i);
+            vr = (vr << 2) | (c ^ 2u);
+        }
+    }
+    for (uint64_t j = 0; j < nk; ++j) {
+        uint32_t a = codes[j + k - 1], r = codes[j];
+        uint32_t fw_out = rotl32(fw, 1) ^ NT_F[a];
+        uint32_t rc_out = rotl32(rc, 31) ^ c_rot[a];
+        uint32_t h = (fw_out + rc_out) >> 16;
+        ws->keyl[j] = ((uint64_t)h << 32) | j;
+        ws->keyr[j] = ((uint64_t)(0xFFFFu - h) << 32) | j;
+        fw = fw_out ^ f_rot[r];
+        rc = rc_out ^ c_tab[r];
+        if (small_k) {
+            vf |= (uint64_t)a << (2 * (k - 1));
+            vr = ((vr << 2) | (a ^ 2u)) & kmask;
+            ws->kf[j] = vf;
+            ws->kr[j] = vr;
+            vf >>= 2;
+        }
+    }
+    /* suffix minima / maxima inside blocks of w k-mers; the prefix side is carried along the scan below */
+    for (uint64_t b = 0; b < nk; b += w) {
+        uint64_t e = b + w < nk ? b + w : nk;
+        uint64_t ml = ~0ull, mr = 0;
+        for (uint64_t j = e; j-- > b;) {
+            ml = ws->keyl[j] < ml ? ws->keyl[j] : ml;
+            mr = ws->keyr[j] > mr ? ws->keyr[j] : mr;
+            ws->sufl[j] = ml;
+            ws->sufr[j] = mr;
+        }
+    }
+    uint64_t tg = 0;
+    for (uint64_t t = 0; t + 1 < l; ++t) tg += (codes[t] >> 1) & 1u;
+    uint64_t pl = ~0ull, pr = 0; /* prefix min / max of the block that holds the window's last k-mer */
+    for (uint64_t j = 0; j + 1 < w; ++j) { /* k-mers 0..w-2 all lie in block 0 */
+        pl = ws->keyl[j] < pl ? ws->keyl[j] : pl;
+        pr = ws->keyr[j] > pr ? ws->keyr[j] : pr;
+    }
+    int have_prev = 0;
+    uint64_t prev = 0;
+    for (uint64_t i = 0; i < nw; ++i) {
+        const uint64_t j = i + w - 1; /* last k-mer of window i */
+        if (j % w == 0) {
+            pl = ~0ull;
+            pr = 0;
+        }
+        pl = ws->keyl[j] < pl ? ws->keyl[j] : pl;
+        pr = ws->keyr[j] > pr ? ws->keyr[j] : pr;
+        tg += (codes[i + l - 1] >> 1) & 1u;
+        uint64_t best;
+        if (i % w == 0) { /* the window is exactly one block */
+            best = (2 * tg > l) ? (ws->sufl[i] & 0xFFFFFFFFu) : (ws->sufr[i] & 0xFFFFFFFFu);
+        } else {
+            uint64_t ml = ws->sufl[i] < pl ? ws->sufl[i] : pl;
+            uint64_t mr = ws->sufr[i] > pr ? ws->sufr[i] : pr;
+            best = (2 * tg > l) ? (ml & 0xFFFFFFFFu) : (mr & 0xFFFFFFFFu);
+        }
+        tg -= (codes[i] >> 1) & 1u;
+        if (have_prev && prev == best) continue;
+        prev = best;
+        have_prev = 1;
+        if (ws->lastbad[best + k - 1] >= (int64_t)best) continue; /* A5 */
+        uint64_t hv;
+        if (small_k) {
+            uint64_t a = ws->kf[best], b = ws->kr[best];
+            hv = dor_xxh3_64_u64(a < b ? a : b);
+        } else {
+            hv = dor_kmer_hash(codes + best, k);
+        }
+        ws->hashes[ws->n_hashes++] = hv;
+    }
+    return DOR_OK;
+}
+
+static uint64_t tuned_distinct_hits(tuned_ws *ws, const dor_set *index) {
+    const uint64_t n = ws->n_hashes;
+    uint64_t need = 16;
+    while (need < 2 * n + 2) need <<= 1;
+    if (need > ws->seen_mask + 1 || !ws->seen_key) {
+        free(ws->seen_key);
+        free(ws->seen_tag);
+        ws->seen_key = (uint64_t *)malloc(need * sizeof(uint64_t));
+        ws->seen_tag = (uint32_t *)calloc(need, sizeof(uint32_t));
+        ws->seen_mask = need - 1;
+        ws->epoch = 0;
+        if (!ws->seen_key || !ws->seen_tag) return UINT64_MAX;
+    }
+    if (++ws->epoch == 0) { /* tag wrap: clear once every 2^32 units */
+        memset(ws->seen_tag, 0, (ws->seen_mask + 1) * sizeof(uint32_t));
+        ws->epoch = 1;
+    }
+    /* small units use a small prefix of the table: fewer cache lines touched */
+    uint64_t mask = 15;
+    while (mask + 1 < 2 * n + 2) mask = mask * 2 + 1;
+    uint64_t hits = 0;
+    for (uint64_t q = 0; q < n; ++q) {
+        const uint64_t h = ws->hashes[q];
+        if (!dor_set_contains(index, h)) continue;
+        uint64_t i = mix64(h) & mask;
+        for (;;) {
+            if (ws->seen_tag[i] != ws->epoch) {
+                ws->seen_tag[i] = ws->epoch;
+                ws->seen_key[i] = h;
+                hits++;
+                break;
+            }
+            if (ws->seen_key[i] == h) break;
+            i = (i + 1) & mask;
+        }
+    }
+    return hits;
+}
+
+typedef struct tuned_job {
+    const dor_set *index;
+    const uint8_t *bases;
+    const uint64_t *offsets;
+    const uint32_t *unit_id;
+    uint64_t n_reads;
+    const dor_params *p;
+    uint8_t *keep;
+    uint32_t *hits, *total;
+    uint64_t *cursor; /* shared: next read to hand out */
+    int rc;
+} tuned_job;
+
+#define TUNED_CHUNK 2048
+
+static void *tuned_worker(void *arg) {
+    tuned_job *j = (tuned_job *)arg;
+    tuned_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    j->rc = DOR_OK;
+    for (;;) {
+        uint64_t r0 = __atomic_fetch_add(j->cursor, TUNED_CHUNK, __ATOMIC_RELAXED);
+        if (r0 >= j->n_reads) break;
+        uint64_t r1 = r0 + TUNED_CHUNK < j->n_reads ? r0 + TUNED_CHUNK : j->n_reads;
+        /* a unit belongs to the chunk that holds its first read */
+        if (j->unit_id) {
+            while (r0 < r1 && r0 > 0 && j->unit_id[r0] == j->unit_id[r0 - 1]) r0++;
+            while (r1 < j->n_reads && j->unit_id[r1] == j->unit_id[r1 - 1]) r1++;
+        }
+        uint64_t r = r0;
+        while (r < r1) {
+            uint64_t u = j->unit_id ? j->unit_id[r] : r;
+            uint64_t e = r + 1;
+            if (j->unit_id)
+                while (e < r1 && j->unit_id[e] == u) e++;
+            ws.n_hashes = 0;
+            for (uint64_t q = r; q < e && j->rc == DOR_OK; ++q)
+                j->rc = tuned_read_hashes(&ws, j->bases + j->offsets[q], j->offsets[q + 1] - j->offsets[q], j->p);
+            if (j->rc != DOR_OK) break;
+            uint64_t h = tuned_distinct_hits(&ws, j->index);
+            if (h == UINT64_MAX) {
+                j->rc = DOR_ERR_NOMEM;
+                break;
+            }
+            j->keep[u] = (uint8_t)dor_meets_filtering_criteria(h, ws.n_hashes, j->p->abs_threshold,
+                                                               j->p->rel_threshold, j->p->deplete);
+            if (j->hits) j->hits[u] = (uint32_t)h;
+            if (j->total) j->total[u] = (uint32_t)ws.n_hashes;
+            r = e;
+        }
+        if (j->rc != DOR_OK) break;
+    }
+    tuned_free(&ws);
+    return NULL;
+}
+
+int dor_filter_batch_tuned_mt(const dor_set *index, const uint8_t *bases, const uint64_t *offsets,
+                              const uint32_t *unit_id, uint64_t n_reads, const dor_params *p, uint8_t *keep,
+                              uint32_t *hits, uint32_t *total, int n_threads) {
+    if (p->k == 0 || p->w == 0 || p->k > 56 || (((uint64_t)p->k + p->w - 1) & 1) == 0) return DOR_ERR_ARG;
+    if (g_nt_rot != 1 || g_cmp_mask != 0xFFFF0000u || g_combine_xor) return DOR_ERR_ARG; /* default rules only */
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    tuned_job *jobs = (tuned_job *)malloc(sizeof(tuned_job) * (size_t)n_threads);
+    if (!th || !jobs) {
+        free(th);
+        free(jobs);
+        return DOR_ERR_NOMEM;
+    }
+    uint64_t cursor = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t] = (tuned_job){index, bases, offsets, unit_id, n_reads, p, keep, hits, total, &cursor, 0};
+        pthread_create(&th[t], NULL, tuned_worker, &jobs[t]);
+    }
+    int rc = DOR_OK;
+    for (int t = 0; t < n_threads; ++t) {
+        pthread_join(th[t], NULL);
+        if (jobs[t].rc != DOR_OK) rc = jobs[t].rc;
+    }
+    free(th);
+    free(jobs);
     return rc;
 }

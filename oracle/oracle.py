@@ -90,6 +90,11 @@ def lib():
     L.dor_filter_batch_mt.restype = C.c_int
     L.dor_filter_batch_mt.argtypes = [
         C.c_void_p, u8p, u64p, u32p, C.c_uint64, C.POINTER(Params), u8p, u32p, u32p, C.c_int]
+    L.dor_filter_batch_tuned_mt.restype = C.c_int
+    L.dor_filter_batch_tuned_mt.argtypes = [
+        C.c_void_p, u8p, u64p, u32p, C.c_uint64, C.POINTER(Params), u8p, u32p, u32p, C.c_int]
+    L.dor_set_variant.restype = C.c_int
+    L.dor_set_variant.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.dor_should_keep_hashes.restype = C.c_int
     L.dor_should_keep_hashes.argtypes = [
         C.c_void_p, u64p, u64p, C.c_uint64, C.c_uint64, C.c_double, C.c_int, u8p, u32p, u32p]
@@ -113,6 +118,16 @@ def _bytes_arr(seq):
     if isinstance(seq, np.ndarray):
         return np.ascontiguousarray(seq, dtype=np.uint8)
     return np.frombuffer(bytes(seq), dtype=np.uint8) if len(seq) else np.zeros(0, np.uint8)
+
+
+VARIANTS = [(rot, bits, comb) for rot in (1, 7) for bits in (16, 32) for comb in ("add", "xor")]
+DEFAULT_VARIANT = (1, 16, "add")
+
+
+def set_variant(nt_rot=1, cmp_bits=16, combine="add"):
+    """The three details of A4 the reference's tests cannot separate (deacon_oracle.c, dor_set_variant)."""
+    if lib().dor_set_variant(nt_rot, cmp_bits, {"add": 0, "xor": 1}[combine]) != 0:
+        raise ValueError("bad minimizer variant")
 
 
 def xxh3_64_u64(v):
@@ -265,8 +280,9 @@ def concat_reads(reads):
 
 
 def filter_batch(index, bases, offsets, unit_id=None, abs_threshold=2, rel_threshold=0.01,
-                 prefix_length=0, deplete=False, threads=1):
-    """Per-unit (keep, hits, total): A1-A8 end to end on the CPU."""
+                 prefix_length=0, deplete=False, threads=1, tuned=False):
+    """Per-unit (keep, hits, total): A1-A8 end to end on the CPU.  tuned: the "port-tuned" form of the same
+    arithmetic (dor_filter_batch_tuned_mt), default A4 rules only."""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n_reads = len(offsets) - 1
@@ -282,7 +298,11 @@ def filter_batch(index, bases, offsets, unit_id=None, abs_threshold=2, rel_thres
     if len(bases) == 0:
         bases = np.zeros(1, np.uint8)
     uid = _p(unit_id, C.c_uint32) if unit_id is not None else None
-    if threads > 1:
+    if tuned:
+        rc = lib().dor_filter_batch_tuned_mt(index._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), uid,
+                                             n_reads, C.byref(p), _p(keep, C.c_uint8), _p(hits, C.c_uint32),
+                                             _p(total, C.c_uint32), threads)
+    elif threads > 1:
         rc = lib().dor_filter_batch_mt(index._h, _p(bases, C.c_uint8), _p(offsets, C.c_uint64), uid,
                                        n_reads, C.byref(p), _p(keep, C.c_uint8), _p(hits, C.c_uint32),
                                        _p(total, C.c_uint32), threads)

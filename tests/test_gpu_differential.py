@@ -59,6 +59,29 @@ def random_case(rng, genome):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DCN_FUZZ_SEEDS", "12"))))  # more seeds for a soak run
 def test_differential(oracle, dcn, seed, monkeypatch):
+    run_seed(oracle, dcn, seed, monkeypatch, 10)
+
+
+from oracle.oracle import DEFAULT_VARIANT, VARIANTS  # noqa: E402
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "rot%d-cmp%d-%s" % v)
+def test_differential_under_every_minimizer_variant(oracle, dcn, variant, monkeypatch):
+    """The parity-pinning switch (dcn_set_minimizer_variant / dor_set_variant): GPU == oracle under each of the eight
+    settings of (ntHash rotation, compared hash bits, fw/rc combination), so that a run of the real crates which
+    contradicts the default costs a switch in both, not a rewrite (tests/test_crate_vectors.py)."""
+    oracle.set_variant(*variant)
+    dcn.set_minimizer_variant(*variant)
+    try:
+        assert dcn.get_minimizer_variant() == variant
+        for seed in (100 + VARIANTS.index(variant), 200 + VARIANTS.index(variant)):
+            run_seed(oracle, dcn, seed, monkeypatch, 5)
+    finally:
+        oracle.set_variant(*DEFAULT_VARIANT)
+        dcn.set_minimizer_variant(*DEFAULT_VARIANT)
+
+
+def run_seed(oracle, dcn, seed, monkeypatch, n_cases):
     rng = np.random.default_rng(1000 + seed)
     genome = random_reads(rng, 1, 60_000, 60_000)[0]
     monkeypatch.setenv("DCN_TILE_WINDOWS", str(int(rng.choice([16, 64, 256, 512, 2048]))))
@@ -70,7 +93,7 @@ def test_differential(oracle, dcn, seed, monkeypatch):
     # table load: 2 slots per key makes most probes of a present key walk past a full home group, 8 almost none
     monkeypatch.setenv("DCN_TABLE_SLOTS_PER_KEY", str(int(np.random.default_rng(seed).choice([2, 4, 8]))))
     indexes = {}
-    for case in range(10):
+    for case in range(n_cases):
         k, w, reads, uid, params = random_case(rng, genome)
         if (k, w) not in indexes:
             oidx = oracle.Index.build([genome], k=k, w=w)

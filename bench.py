@@ -573,7 +573,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other configs and the host-path measurements that follow the headline at N = 1")
-    ap.add_argument("--extras", default="long,paired,host_path,host1g,host95,union950m",
+    ap.add_argument("--extras", default="long,paired,host_path,cli,host1g,host95,union950m",
                     help="which of the extra measurements to run (comma separated)")
     args = ap.parse_args()
 
@@ -687,7 +687,7 @@ def main():
             oidx = None
 
         # ---- everything below runs after the contract's timed region and never enters `value` --------------------------
-        workloads, host_path = {}, None
+        workloads, host_path, cli = {}, None, None
         short_batches = batches if args.workload == "short" else None
         del keys
         for e in extras:
@@ -708,10 +708,29 @@ def main():
                     if short_batches is None:
                         short_batches = make_batches("short", genome_dev, 2_000_000, seeds["short"], device)
                     host_path = run_host_path(index, short_batches, P_SHORT, oidx, cores)
+                elif e == "cli":
+                    # `deacon-hip` file to file, as a user runs it (bench_cli.py): configs[0] at its stated shape, then
+                    # search / host depletion / two files of mates against this index written as an index FILE
+                    import bench_cli
+                    if oidx is not None:
+                        del oidx  # 8.6 GB of host memory the tool's page cache can use; the legs below build their own small sets
+                        oidx = None
+                    cli = {"plumbing": bench_cli.plumbing(threads=cores)}
+                    log(f"cli.plumbing: decisions_match={cli['plumbing']['decisions_match']} ({time.time() - t_e:.0f} s)")
+                    sizes = None
+                    if os.environ.get("DCN_BENCH_CLI_READS"):  # smaller files for a rehearsal
+                        n_ = int(os.environ["DCN_BENCH_CLI_READS"])
+                        sizes = {"search50": n_, "deplete95": n_, "paired": n_ // 2}
+                    cli.update(bench_cli.file_to_file(index, genome_dev, host_keys, n_rand, make_reads, make_pairs,
+                                                      touchable_oracle_index, cores, sizes=sizes, log=log))
+                    cli["decisions_match"] = all(v.get("decisions_match", True) for v in cli.values() if isinstance(v, dict))
+                    cli["wall_s"] = time.time() - t_e
             except Exception as ex:  # an extra that fails must not take the contract's line with it
                 log(f"extra '{e}' failed: {ex!r}")
                 if e == "host_path":
                     host_path = {"error": repr(ex)}
+                elif e == "cli":
+                    cli = {"error": repr(ex), "decisions_match": False}
                 else:
                     workloads[e] = {"error": repr(ex)}
                 torch.cuda.empty_cache()
@@ -793,6 +812,8 @@ def main():
             out["workloads"] = workloads
         if host_path:
             out["host_path"] = host_path
+        if cli:
+            out["cli"] = cli
         out["bench_wall_s"] = time.time() - T0
         print(json.dumps(out), flush=True)
     if world > 1:

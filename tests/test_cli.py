@@ -586,3 +586,34 @@ def test_paired_files_in_parallel_match_the_record_reader(tmp_path, monkeypatch)
     r2.write_bytes(b"".join(l2 + l2[:2]))
     p = run("filter", idx, r1, r2, check=False)
     assert p.returncode != 0 and b"more records" in p.stderr
+
+
+# ---- BASELINE.json configs[0] at its stated shape ------------------------------------------------
+def test_fastq_record_helpers_round_trip(tmp_path):
+    import bench_cli
+    rng = np.random.default_rng(0)
+    seqs = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (1000, bench_cli.READ_LEN))]
+    rec = bench_cli.fastq_records(seqs, first_id=123_456_000)
+    lines = rec.tobytes().split(b"\n")
+    assert lines[0] == b"@123456000" and lines[1] == seqs[0].tobytes() and lines[2] == b"+" and lines[3] == b"I" * 150
+    p = tmp_path / "x.fq"
+    rec[::3].tofile(p)
+    assert bench_cli.ids_of_output(p).tolist() == list(range(123_456_000, 123_457_000, 3))
+    rec[:10].tofile(p)
+    assert bench_cli.ids_of_output(p, limit_id=123_456_004).tolist() == [123_456_000 + i for i in range(4)]
+
+
+@pytest.mark.gpu
+def test_config1_plumbing_at_its_stated_shape(tmp_path):
+    """4,641,652 bp genome -> `deacon-hip index build` -> 10,000 x 150 bp FASTQ, -a 2 -r 0.01, search and -d: the index
+    key set and the ids of the kept records of both modes equal the oracle's (the leg bench.py reports as cli.plumbing)."""
+    import bench_cli
+    r = bench_cli.plumbing(str(tmp_path), threads=4)
+    assert r["index_build"]["key_set_equals_oracle"] and r["index_build"]["keys"] > 500_000
+    for mode in ("search", "deplete"):
+        assert r[mode]["kept_ids_equal_oracle"], r[mode]
+        assert r[mode]["seqs_in"] == 10_000 and r[mode]["bp_in"] == 1_500_000
+    # the two modes are complements of each other, and the reads drawn from the genome are the ones found
+    assert r["search"]["seqs_out"] + r["deplete"]["seqs_out"] == 10_000
+    assert 4_900 <= r["search"]["seqs_out"] <= 5_100
+    assert r["decisions_match"]

@@ -472,7 +472,7 @@ def run_host_path(index, batches, params, oidx, cores, calls=12):
         pins.append((pb, pp, pm))
     tp = time.time()
     for h, (pb, pp, pm) in zip(host, pins):
-        dcn._native.check(dcn._native.lib().dcn_pack_ascii(h.ctypes.data, n_bases, pp.array.ctypes.data, pm.array.ctypes.data))
+        dcn._native.check(dcn._native.lib().dcn_pack_ascii(h.ctypes.data, n_bases, pp.array.ctypes.data, pm.array.ctypes.data, None))
     pack_s = (time.time() - tp) / len(host)
     poff = dcn.PinnedBuffer(n_reads + 1, np.uint64)
     poff.array[:] = off

@@ -88,7 +88,7 @@ _SIGNATURES = {
     "dcn_filter_batch_packed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp]),
     "dcn_filter_batch_packed_submit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_uint32, C.POINTER(Params), _vp, _vp, _vp,
                                                  _u64p]),
-    "dcn_pack_ascii": (C.c_int, [_vp, C.c_uint64, _vp, _vp]),
+    "dcn_pack_ascii": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _u32p]),
     "dcn_stats_allreduce": (C.c_int, [C.POINTER(_vp), C.c_int, _u64p]),
     "dcn_index_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dcn_index_memory": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),

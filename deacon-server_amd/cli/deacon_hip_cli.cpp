@@ -20,6 +20,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
+#include <sys/vfs.h>
 #include <unistd.h>
 #include <zlib.h>
 #if defined(__x86_64__)
@@ -1203,7 +1204,19 @@ class MappedOutput {
         fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
         if (fd_ < 0) die("Failed to create output file: " + path);
         struct stat st;
-        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode) || ftruncate(fd_, (off_t)reserve) != 0) {  // a pipe, a device, ...
+        // Only filesystems that report a failed allocation when the page is touched (SIGBUS, handled below) are written
+        // through a mapping.  Anything else -- NFS, FUSE, CIFS, a quota enforced at writeback -- would let the run print
+        // "Retained ..." and exit 0 over a short file; there the gather writer's write(2) reports the error as the
+        // reference's writer does.  DCN_CLI_MMAP_ANY_FS=1 maps regardless and pays for an msync at the end instead.
+        struct statfs sfs;
+        const bool local = fstatfs(fd_, &sfs) == 0 &&
+                           (sfs.f_type == 0x01021994 /* tmpfs */ || sfs.f_type == 0xEF53 /* ext2/3/4 */ ||
+                            sfs.f_type == 0x58465342 /* xfs */ || sfs.f_type == 0x9123683E /* btrfs */ ||
+                            sfs.f_type == 0x794C7630 /* overlayfs */ || sfs.f_type == 0xF2F52010 /* f2fs */ ||
+                            sfs.f_type == 0x2FC12FC1 /* zfs */ || sfs.f_type == 0x858458F6 /* ramfs */);
+        sync_at_end_ = !local;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode) || (!local && !std::getenv("DCN_CLI_MMAP_ANY_FS")) ||
+            ftruncate(fd_, (off_t)reserve) != 0) {  // a pipe, a device, a remote filesystem ...
             ::close(fd_);
             fd_ = -1;
             return false;
@@ -1235,6 +1248,16 @@ class MappedOutput {
             _exit(1);
         };
         sigaction(SIGBUS, &sa, nullptr);
+        // an interrupted run must not leave the sparse reservation (several times the input's size) behind
+        struct sigaction si;
+        std::memset(&si, 0, sizeof si);
+        si.sa_handler = [](int sig) {
+            int fd = g_sparse_out_fd.exchange(-1);
+            if (fd >= 0 && ftruncate(fd, 0) != 0) {
+            }
+            _exit(128 + sig);
+        };
+        for (int sig : {SIGINT, SIGTERM, SIGHUP}) sigaction(sig, &si, nullptr);
         return true;
     }
     char *at(uint64_t off, uint64_t len) {
@@ -1243,8 +1266,12 @@ class MappedOutput {
     }
     void finish(uint64_t bytes) {
         if (fd_ < 0) return;
+        // a filesystem that defers allocation errors to writeback only shows them to msync / fsync
+        if (sync_at_end_ && bytes && msync(data_, bytes, MS_SYNC) != 0) die("write error");
         g_sparse_out_fd = -1;
-        if (munmap(data_, reserve_) != 0 || ftruncate(fd_, (off_t)bytes) != 0 || ::close(fd_) != 0) die("write error");
+        if (munmap(data_, reserve_) != 0 || ftruncate(fd_, (off_t)bytes) != 0) die("write error");
+        if (sync_at_end_ && fdatasync(fd_) != 0) die("write error");
+        if (::close(fd_) != 0) die("write error");
         fd_ = -1;
     }
     bool active() const { return fd_ >= 0; }
@@ -1253,6 +1280,7 @@ class MappedOutput {
     int fd_ = -1;
     char *data_ = nullptr;
     uint64_t reserve_ = 0;
+    bool sync_at_end_ = false;
 };
 
 std::string fmt_duration(double s) {  // like Rust's {:.2?} for Duration

@@ -1154,9 +1154,19 @@ struct HostInput {
     uint32_t n_reads = 0;
 };
 
+int alloc_slot_impl(dcn_ctx *c, int si);
+
+// a slot is either complete or empty: a failure half-way (slot 1 duplicates every max_bases-sized buffer, so it is the
+// allocation most likely to fail) releases what it got, and the next submit starts from null pointers again
 int alloc_slot(dcn_ctx *c, int si) {
+    if (c->slots[si].allocated) return DCN_OK;
+    const int rc = alloc_slot_impl(c, si);
+    if (rc != DCN_OK) free_slot_buffers(c->slots[si]);
+    return rc;
+}
+
+int alloc_slot_impl(dcn_ctx *c, int si) {
     dcn_slot &sl = c->slots[si];
-    if (sl.allocated) return DCN_OK;
     const uint64_t MR = c->max_reads;
     if (si == 0) { // the context's own buffers
         sl.d_ascii = c->d_ascii;
@@ -1576,13 +1586,17 @@ extern "C" int dcn_filter_batch_packed(dcn_ctx *ctx, const uint32_t *packed, con
     return wait_impl(ctx, ticket);
 }
 
-extern "C" int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uint32_t *invmask) {
+extern "C" int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uint32_t *invmask,
+                              uint32_t *saw_newline) {
+    if (saw_newline) *saw_newline = 0;
     if (n_bases > 0 && (!bases || !packed || !invmask)) return dcn_fail(DCN_ERR_ARG, "bases/packed/invmask is NULL");
     const uint64_t G = (n_bases + 31) / 32;
+    std::atomic<uint32_t> nl{0};
     HostPool::get().run([&](int i, int nt) {
         const uint64_t per = (G + nt - 1) / nt, lo = std::min<uint64_t>(G, per * i), hi = std::min<uint64_t>(G, lo + per);
-        dcn_host_pack_groups(bases, n_bases, lo, hi, packed + 2 * lo, invmask + lo);
+        if (dcn_host_pack_groups(bases, n_bases, lo, hi, packed + 2 * lo, invmask + lo)) nl.store(1, std::memory_order_relaxed);
     }, G < 4096);
+    if (saw_newline) *saw_newline = nl.load();
     return DCN_OK;
 }
 

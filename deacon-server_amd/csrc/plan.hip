@@ -163,6 +163,10 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
 #endif
 constexpr uint32_t DCN_LDS_SET_SLOTS = 1u << DCN_LDS_SET_LOG2;
 constexpr uint32_t DCN_LDS_SET_MAX = DCN_LDS_SET_SLOTS * 7 / 10 - 33; // hits deduplicated in LDS (load <= 0.68): 1400 for 2048 slots
+// pass A walks a unit's tiles 64 at a time with one wave, a dependent pair of loads per step: a unit of more tiles than
+// this (a read beyond ~260 kbp at 256 windows per tile) goes to pass B's one-wave-per-64-tiles form however few hits it
+// has, so that a chromosome-sized read with a handful of hits is not one wave's serial tail
+constexpr uint32_t DCN_LDS_WALK_MAX_TILES = 1024;
 
 __device__ inline uint32_t set_slot_of(uint64_t h, uint32_t cap) {
     uint32_t lo = (uint32_t)h, hi = (uint32_t)(h >> 32);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
             if (lane == 0) a.caps[u] = 0;
             continue;
         }
-        if (count == 0xFFFFFFFFu || H > DCN_LDS_SET_MAX) {
+        if (count == 0xFFFFFFFFu || H > DCN_LDS_SET_MAX || count > DCN_LDS_WALK_MAX_TILES) {
             // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor (all regions are
             // cleared by one small kernel between the passes)
             uint32_t cap = 64;
@@ -327,8 +331,9 @@ __global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots
 
 // Pass B, one wave per work item (64 consecutive tiles of a unit with a global set): find the runs hanging on those
 // tiles and CAS-insert them; one atomicAdd of the number of new keys per wave.  Units whose tiles are not contiguous
-// in the tile array (a unit of three or more reads cut by a planning block; never a single read or a pair) have no
-// tile list: if there is one, every tile of the batch is looked at.
+// in the tile array have no tile list: if there is one, every tile of the batch is looked at.  That is a unit of two or
+// more reads cut by a planning block's boundary: never a single read, never a pair of a batch made of pairs only (the
+// block size is even), but a pair CAN be cut when a batch mixes unit sizes (units of one and of two reads).
 __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
     if (a.status->set_cursor == 0 || a.status->rec_overflow) return;
     const uint32_t NB = a.status->n_big;

@@ -48,14 +48,20 @@ def concat_reads(reads):
     return bases, offsets
 
 
-def pack_ascii(bases):
+def pack_ascii(bases, allow_newline=False):
     """Concatenated ASCII -> (packed u32[2*ceil(n/32)], invmask u32[ceil(n/32)]) in the layout
-    dcn_filter_batch_packed takes (PackedSeqVec::from_ascii + the mask loop, filter_common.rs:238-258)."""
+    dcn_filter_batch_packed takes (PackedSeqVec::from_ascii + the mask loop, filter_common.rs:238-258).
+    A newline byte in the input raises: the ASCII entry points strip one from the end of a read
+    (filter_common.rs:229), the packed ones cannot, so such a batch must go through filter_batch / submit."""
     bases = _as_u8(bases)
     g = (len(bases) + 31) // 32
     packed = np.zeros(max(2 * g, 1), np.uint32)
     mask = np.zeros(max(g, 1), np.uint32)
-    N.check(N.lib().dcn_pack_ascii(_ptr(bases) if len(bases) else None, len(bases), _ptr(packed), _ptr(mask)))
+    nl = C.c_uint32()
+    N.check(N.lib().dcn_pack_ascii(_ptr(bases) if len(bases) else None, len(bases), _ptr(packed), _ptr(mask), C.byref(nl)))
+    if nl.value and not allow_newline:
+        raise ValueError("pack_ascii: the batch holds a newline byte; a read ending in one is shortened by the ASCII entry "
+                         "points (filter_common.rs:229) but not by the packed ones -- strip line ends or use filter_batch")
     return packed[:2 * g], mask[:g]
 
 

@@ -200,9 +200,9 @@ int dcn_filter_batch_wait(dcn_ctx *ctx, uint64_t ticket);
  *   invmask  1 bit per base, bit i%32 of invmask[i/32] set iff byte i is not one of ACGTacgt
  *   offsets / unit_id / outputs as for dcn_filter_batch (offsets are BASE indices into the stream)
  * Both arrays must be allocated in whole 32-base groups: 2 * ceil(n_bases/32) and ceil(n_bases/32) words
- * (dcn_pack_ascii fills them).  Reads must not end in '
-' (src/filter_common.rs:229 strips one from the ASCII;
- * a packed stream cannot show it).  The pack kernel is skipped; 0.375 bytes per base cross the link. */
+ * (dcn_pack_ascii fills them).  Reads must not end in a newline byte, 0x0A (src/filter_common.rs:229 strips one from
+ * the ASCII; a packed stream cannot show it: dcn_pack_ascii reports whether it met one).  The pack kernel is skipped;
+ * 0.375 bytes per base cross the link. */
 int dcn_filter_batch_packed(dcn_ctx *ctx, const uint32_t *packed, const uint32_t *invmask, const uint64_t *offsets,
                             const uint32_t *unit_id, uint32_t n_reads, const dcn_params *params, uint8_t *keep,
                             uint32_t *hits, uint32_t *total);
@@ -213,8 +213,11 @@ int dcn_filter_batch_packed_submit(dcn_ctx *ctx, const uint32_t *packed, const u
 
 /* Host-side packer producing exactly that layout from concatenated ASCII (AVX2 + BMI2 where the CPU has them,
  * split over the library's host threads, DCN_HOST_THREADS).  Input formatting only: nothing here hashes or
- * decides.  packed / invmask: 2 * ceil(n_bases/32) and ceil(n_bases/32) u32 words. */
-int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uint32_t *invmask);
+ * decides.  packed / invmask: 2 * ceil(n_bases/32) and ceil(n_bases/32) u32 words.  saw_newline (may be NULL)
+ * receives 1 if some byte of the input was 0x0A, else 0: a read that ENDS in one is shortened by the ASCII entry
+ * points (src/filter_common.rs:229) and cannot be by the packed ones, so a caller whose record buffers may carry
+ * line ends must strip them, or send that batch through dcn_filter_batch, when the flag comes back set. */
+int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uint32_t *invmask, uint32_t *saw_newline);
 
 /* Same computation on inputs already resident in device memory (all pointers are DEVICE pointers on the
  * context's GPU; d_unit_id / d_hits / d_total may be NULL).  n_bases = offsets[n_reads], n_units = number

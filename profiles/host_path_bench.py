@@ -31,7 +31,7 @@ for h in host:
     pb = dcn.PinnedBuffer(n_bases, np.uint8)
     pb.array[:] = h
     pp, pm = dcn.PinnedBuffer(2 * G, np.uint32), dcn.PinnedBuffer(G, np.uint32)
-    dcn._native.check(lib.dcn_pack_ascii(h.ctypes.data, n_bases, pp.array.ctypes.data, pm.array.ctypes.data))
+    dcn._native.check(lib.dcn_pack_ascii(h.ctypes.data, n_bases, pp.array.ctypes.data, pm.array.ctypes.data, None))
     pins.append((pb, pp, pm))
 poff = dcn.PinnedBuffer(n_reads + 1, np.uint64)
 poff.array[:] = offsets

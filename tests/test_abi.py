@@ -114,3 +114,75 @@ def test_c_caller_links_and_runs(tmp_path, dcn):
     p = subprocess.run([str(exe)], capture_output=True, text=True)
     assert p.returncode == 0, (p.returncode, p.stdout, p.stderr)
     assert p.stdout.startswith("deacon-hip ")
+
+
+# ---- INTEGRATION.md's extern "C" block against the header (21 of 38 exports were bound) -------------------------
+def _c_declarations(header_text):
+    """name -> (return type, [argument types]) of every function the header declares, types as normalised C strings"""
+    import re
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^([A-Za-z_][A-Za-z0-9_ \*]*?)\b(dcn_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.M | re.S):
+        ret, name, args = " ".join(m.group(1).split()), m.group(2), " ".join(m.group(3).split())
+        argv = [] if args in ("void", "") else [a.strip() for a in args.split(",")]
+        out[name] = (ret, argv)
+    return out
+
+
+def _rust_of_c(ctype):
+    """'const uint64_t *keys' -> '*const u64' (the Rust FFI spelling of a C parameter or return type)"""
+    import re
+    t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*\s*\[[^\]]*\]\s*$", "*", ctype.strip())  # `name[N]` parameter = pointer
+    toks = re.findall(r"const|\*|[A-Za-z_][A-Za-z0-9_]*", t)
+    base = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "int": "c_int", "char": "c_char", "void": "c_void",
+            "float": "f32", "double": "f64", "dcn_index": "dcn_index", "dcn_ctx": "dcn_ctx", "dcn_params": "dcn_params"}
+    # drop a trailing parameter name (an identifier that is not a known type word, after the type is complete)
+    while toks and toks[-1] not in base and toks[-1] not in ("const", "*"):
+        toks.pop()
+    const_next, cur = False, None
+    for tk in toks:
+        if tk == "const":
+            const_next = True
+        elif tk == "*":
+            cur = ("*const " if const_next else "*mut ") + cur
+            const_next = False
+        else:
+            cur = base[tk]
+    return cur
+
+
+def _rust_declarations(md_text):
+    import re
+    block = md_text[md_text.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    block = re.sub(r"//[^\n]*", "", block)
+    out = {}
+    for m in re.finditer(r"pub fn (dcn_[a-z0-9_]+)\s*\(([^)]*)\)\s*(?:->\s*([^;]+?))?\s*;", block, flags=re.S):
+        args = [" ".join(a.split(":", 1)[1].split()) for a in m.group(2).split(",") if a.strip()]
+        out[m.group(1)] = (" ".join(m.group(3).split()) if m.group(3) else None, args)
+    return out
+
+
+def test_type_translator():
+    assert _rust_of_c("const uint64_t *keys") == "*const u64"
+    assert _rust_of_c("dcn_index **out") == "*mut *mut dcn_index"
+    assert _rust_of_c("const dcn_index *const *inputs") == "*const *const dcn_index"
+    assert _rust_of_c("dcn_ctx *const *ctxs") == "*const *mut dcn_ctx"
+    assert _rust_of_c("uint64_t counters[DCN_N_STATS]") == "*mut u64"
+    assert _rust_of_c("double stage_ms[DCN_N_STAGES]") == "*mut f64"
+    assert _rust_of_c("void **out") == "*mut *mut c_void"
+    assert _rust_of_c("const char *") == "*const c_char"
+    assert _rust_of_c("float entropy_threshold") == "f32"
+    assert _rust_of_c("int") == "c_int"
+
+
+def test_integration_md_binds_every_export(dcn):
+    root = os.path.dirname(os.path.dirname(dcn._native.HEADER_PATH))
+    c = _c_declarations(open(dcn._native.HEADER_PATH).read())
+    r = _rust_declarations(open(os.path.join(root, "INTEGRATION.md")).read())
+    assert sorted(c) == dcn._native.declared_symbols()
+    assert sorted(r) == sorted(c), {"unbound": sorted(set(c) - set(r)), "unknown": sorted(set(r) - set(c))}
+    for name, (ret, args) in c.items():
+        rret, rargs = r[name]
+        assert rret == (None if ret == "void" else _rust_of_c(ret)), (name, ret, rret)
+        assert rargs == [_rust_of_c(a) for a in args], (name, args, rargs)

@@ -325,6 +325,26 @@ def test_one_very_long_read(oracle, dcn, genome, index_pair):
     assert keep[200] == 0  # -r 0.5: half of its minimizers would have to hit
 
 
+def test_very_long_reads_with_few_hits(oracle, dcn, genome, index_pair):
+    """Reads of more than 1,024 tiles with a handful of hits (a foreign chromosome carrying a few k-mers of the indexed
+    genome, some of them repeated): too few hits for a global set by their number, too many tiles for one wave to walk
+    -- they take the multi-wave pass of the distinct count (plan.hip, DCN_LDS_WALK_MAX_TILES)."""
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(43)
+    reads = []
+    for n, planted in ((300_000, 3), (700_000, 1), (1_500_000, 40), (290_000, 0)):
+        big = bytearray(random_reads(rng, 1, n, n)[0])
+        spots = rng.integers(0, n - 400, planted)
+        for i, s in enumerate(spots):
+            g0 = 5_000 if i % 2 else int(rng.integers(0, len(genome) - 200))  # every second copy is the same stretch
+            big[s:s + 120] = genome[g0:g0 + 120]
+        reads.append(bytes(big))
+    reads += sample_reads(rng, genome, 100, 100, 5_000)
+    proc = dcn.FilterProcessor(gidx, abs_threshold=2, rel_threshold=0.0, max_batch_bases=4 << 20, max_batch_reads=1 << 10)
+    keep, hits, total = check_batch(oracle, proc, oidx, reads)
+    assert 1 <= hits[0] < 40 and 1 <= hits[1] < 20 and hits[3] == 0 and total[2] > 100_000
+
+
 def test_repeats_inside_long_reads_are_counted_once(oracle, dcn, genome, index_pair):
     oidx, gidx = index_pair
     seg = genome[1000:3000]

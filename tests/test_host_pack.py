@@ -24,10 +24,31 @@ def test_pack_ascii_matches_the_definition(dcn, n):
     b = rng.integers(0, 256, n, dtype=np.uint8)  # every byte value, not only nucleotides
     if n > 100:
         b[::3] = np.frombuffer(b"ACGTacgtNn\n", np.uint8)[rng.integers(0, 11, len(b[::3]))]
-    packed, mask = dcn.pack_ascii(b)
+    packed, mask = dcn.pack_ascii(b, allow_newline=True)
     want_p, want_m = numpy_pack(b)
     assert packed.tolist() == want_p.tolist()
     assert mask.tolist() == want_m.tolist()
+    if (b == 10).any():  # the flag dcn_host_pack_groups returns used to be dropped
+        with pytest.raises(ValueError, match="newline"):
+            dcn.pack_ascii(b)
+    else:
+        dcn.pack_ascii(b)
+
+
+def test_packed_input_with_a_line_end_is_refused(dcn):
+    """A record buffer that still carries its line end must not reach the packed entry points silently: the ASCII
+    ones strip it (src/filter_common.rs:229), a packed stream cannot show where reads end."""
+    with pytest.raises(ValueError, match="newline"):
+        dcn.pack_ascii(b"ACGTACGTAC\n" * 7)
+    for n in (1, 31, 32, 33, 5000, 300_000):  # wherever the byte sits, scalar tail and vector body, every worker's share
+        b = np.full(n, ord("C"), np.uint8)
+        dcn.pack_ascii(b)
+        b[n - 1] = 10
+        with pytest.raises(ValueError):
+            dcn.pack_ascii(b)
+        b[n - 1], b[n // 2] = ord("C"), 10
+        with pytest.raises(ValueError):
+            dcn.pack_ascii(b)
 
 
 def test_pack_ascii_threaded_path_and_codes(dcn):

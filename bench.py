@@ -99,21 +99,44 @@ def host_minimizer_keys(genome_dev, device_index):
     return np.sort(keys)
 
 
-def build_index(genome_dev, n_keys, local_rank):
+def build_index(genome_dev, n_keys, local_rank, world=1, rank=0):
+    """Device table of the synthetic index.  The key array (3.3 GB for panhuman-1's size) is generated ONCE per node:
+    at world > 1 rank 0 writes it to tmpfs and the other ranks map it (one copy in the page cache instead of one
+    generation and one 3.3 GB array per rank); every rank then builds its own replica from it."""
     t0 = time.time()
-    host_keys = host_minimizer_keys(genome_dev, local_rank)
-    n_rand = max(0, n_keys - len(host_keys))
-    keys = np.empty(len(host_keys) + n_rand, np.uint64)
-    keys[:len(host_keys)] = host_keys
-    step = 1 << 27
-    for a in range(0, n_rand, step):
-        m = min(step, n_rand - a)
-        keys[len(host_keys) + a:len(host_keys) + a + m] = mix64_device(1 + a, m, genome_dev.device).cpu().numpy().view(np.uint64)
+    shared = None
+    if world > 1:
+        shared = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                              f"dcn_bench_keys_{os.environ.get('MASTER_PORT', '0')}_{n_keys}.u64")
+    host_keys, n_rand = None, 0
+    if rank == 0:
+        host_keys = host_minimizer_keys(genome_dev, local_rank)
+        n_rand = max(0, n_keys - len(host_keys))
+        n_all = len(host_keys) + n_rand
+        keys = np.lib.format.open_memmap(shared, mode="w+", dtype=np.uint64, shape=(n_all,)) if shared else np.empty(n_all, np.uint64)
+        keys[:len(host_keys)] = host_keys
+        step = 1 << 27
+        for a in range(0, n_rand, step):
+            m = min(step, n_rand - a)
+            keys[len(host_keys) + a:len(host_keys) + a + m] = mix64_device(1 + a, m, genome_dev.device).cpu().numpy().view(np.uint64)
+        if shared:
+            keys.flush()
+    if world > 1:
+        dist.barrier()
+        if rank != 0:
+            keys = np.load(shared, mmap_mode="r")
     t1 = time.time()
     index = dcn.Index.from_keys(keys, K, W, device=local_rank)
-    log(f"index: {len(host_keys):,} host-genome keys + {n_rand:,} mix64 keys generated in {t1 - t0:.1f} s; device table "
-        f"of {index.n_keys:,} distinct keys built in {time.time() - t1:.1f} s")
-    return index, keys, host_keys, n_rand, time.time() - t1
+    build_s = time.time() - t1
+    if world > 1:
+        dist.barrier()
+        if rank == 0:
+            os.unlink(shared)
+    if rank == 0:
+        log(f"index: {len(host_keys):,} host-genome keys + {n_rand:,} mix64 keys generated in {t1 - t0:.1f} s"
+            f"{' (once for the node, shared through ' + os.path.dirname(shared) + ')' if shared else ''}; device table "
+            f"of {index.n_keys:,} distinct keys built in {build_s:.1f} s")
+    return index, keys, host_keys, n_rand, build_s
 
 
 # ---- synthetic reads, generated on the device ---------------------------------------------------------------------
@@ -452,22 +475,35 @@ def cpu_baseline(oidx, cores, batch, params, seconds_target=12.0):
 
 
 # ---- the host boundary: dcn_filter_batch* from host memory, PCIe included ----------------------------------------------
-def run_host_path(index, batches, params, oidx, cores, calls=12):
-    """2 M x 150 bp per call (300 MB of ASCII), three distinct batches rotated, results copied back to the host.
-    Blocking calls, then the submit/wait form with two batches in flight."""
-    n_reads = min(batches[0].n_reads, 2_000_000)
+def run_host_path(index, batches, params, oidx, cores, calls=6, reads_per_call=10_000_000, kinds=("pageable", "pinned", "packed"),
+                  reps=5, world=1, rank=0, coll_device=None):
+    """dcn_filter_batch* from host memory, PCIe included: `reads_per_call` x 150 bp per call (the headline's 10 M-read batch
+    = 1.5 GB of ASCII by default), three distinct batches rotated, results copied back to the host.  Blocking calls,
+    then the submit/wait form with two batches in flight.  Decisions are checked against the oracle on the first 200 k reads
+    of every batch when an oracle set is at hand (N = 1), else against the device-resident run of the same batch.
+    At world > 1 every rank runs this at the same time (barriers around every timed repetition): eight ranks share
+    one host's memory and PCIe root complexes, which is what the per-rank and summed rates show."""
+    n_reads = min(batches[0].n_reads, reads_per_call)
     n_bases = n_reads * READ_LEN
     host = [b.d_bases[:n_bases].cpu().numpy() for b in batches]
     off = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(READ_LEN)
-    want = [oracle_decisions(oidx, h[:200_000 * READ_LEN], off[:200_001], None, params, cores)[0] for h in host]
+    n_chk = min(200_000, n_reads)
+    if oidx is not None:
+        want = [oracle_decisions(oidx, h[:n_chk * READ_LEN], off[:n_chk + 1], None, params, cores)[0] for h in host]
+        checked = f"first {n_chk} reads of each of the {len(host)} batches vs the CPU oracle"
+    else:
+        n_chk = n_reads
+        want = [b.d_keep[:n_reads].cpu().numpy().astype(bool) for b in batches]
+        checked = f"all {n_reads} reads of each of the {len(host)} batches vs the device-resident run of the same batch"
     proc = dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"], deplete=params["deplete"],
                                max_batch_bases=n_bases, max_batch_reads=n_reads)
     G = (n_bases + 31) // 32
     pins = []
     t0 = time.time()
     for h in host:
-        pb = dcn.PinnedBuffer(n_bases, np.uint8)
-        pb.array[:] = h
+        pb = dcn.PinnedBuffer(n_bases, np.uint8) if "pinned" in kinds else None
+        if pb is not None:
+            pb.array[:] = h
         pp, pm = dcn.PinnedBuffer(2 * G, np.uint32), dcn.PinnedBuffer(G, np.uint32)
         pins.append((pb, pp, pm))
     tp = time.time()
@@ -478,8 +514,8 @@ def run_host_path(index, batches, params, oidx, cores, calls=12):
     poff.array[:] = off
     keeps = [dcn.PinnedBuffer(n_reads, np.uint8) for _ in range(2)]
     log(f"host_path: buffers ready in {time.time() - t0:.1f} s; dcn_pack_ascii {n_bases / pack_s / 1e9:.1f} Gbp/s on the host threads")
-    out = {"reads_per_call": n_reads, "bases_per_call": n_bases, "calls": calls,
-           "host_pack_Gbp_per_s": n_bases / pack_s / 1e9,
+    out = {"reads_per_call": n_reads, "bases_per_call": n_bases, "calls": calls, "repetitions": reps,
+           "host_pack_Gbp_per_s": n_bases / pack_s / 1e9, "checked": checked,
            "note": "PCIe-inclusive, results copied back; never the headline `value`"}
     lib, P = dcn._native.lib(), proc._params()
     import ctypes as C
@@ -502,32 +538,49 @@ def run_host_path(index, batches, params, oidx, cores, calls=12):
 
     link_bytes = {"pageable": 0.375 * n_bases + 8 * n_reads, "pinned": 1.0 * n_bases + 8 * n_reads,
                   "packed": 0.375 * n_bases + 8 * n_reads}
+
     def wait(tk):
         dcn._native.check(lib.dcn_filter_batch_wait(proc._h, tk))
 
-    for kind in ("pageable", "pinned", "packed"):
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    def over_ranks(x):
+        """per-rank values of one number (identity at world == 1)"""
+        if world == 1:
+            return [float(x)]
+        t = torch.zeros(world, dtype=torch.float64, device=coll_device)
+        t[rank] = float(x)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t.cpu().tolist()]
+
+    for kind in kinds:
         kb = [np.zeros(n_reads, np.uint8), np.zeros(n_reads, np.uint8)] if kind == "pageable" else [k_.array for k_ in keeps]
-        # untimed: every batch once through both forms, checked against the oracle's decisions on its first 200 k
-        # reads (also warms the second slot, whose buffers are allocated when it is first used)
+        # untimed: every batch once through both forms, checked (also warms the second slot, whose buffers are
+        # allocated when it is first used)
         ok = True
         for i in range(len(host)):
             call(kind, i, kb[0], False)
-            ok = ok and bool((kb[0][:200_000].astype(bool) == want[i]).all())
+            ok = ok and bool((kb[0][:n_chk].astype(bool) == want[i][:n_chk]).all())
         for i in range(0, len(host) + 1, 2):
             tks = [(j, call(kind, j % len(host), kb[j % 2], True)) for j in (i, i + 1)]
             for j, tk in tks:
                 wait(tk)
-                ok = ok and bool((kb[j % 2][:200_000].astype(bool) == want[j % len(host)]).all())
-        # timed: blocking calls, then submit / wait with two batches in flight; five repetitions of `calls` calls each,
-        # the median is reported and all five are listed (a call is 2.5-6 ms of mostly host-side runtime calls: the same
-        # binary on the same box gives 94-124 Gbp/s for packed input from one repetition to the next)
+                ok = ok and bool((kb[j % 2][:n_chk].astype(bool) == want[j % len(host)][:n_chk]).all())
+        # timed: blocking calls, then submit / wait with two batches in flight; `reps` repetitions of `calls` calls each,
+        # the median is reported and all are listed
         def blocking():
+            fence()
             t0 = time.perf_counter()
             for i in range(calls):
                 call(kind, i, kb[0], False)
-            return time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            fence()
+            return dt
 
         def pipelined():
+            fence()
             t0 = time.perf_counter()
             tickets = []
             for i in range(calls):
@@ -536,23 +589,30 @@ def run_host_path(index, batches, params, oidx, cores, calls=12):
                 tickets.append(call(kind, i, kb[i % 2], True))
             for tk in tickets:
                 wait(tk)
-            return time.perf_counter() - t0
+            dt = time.perf_counter() - t0
+            fence()
+            return dt
 
-        reps_b = sorted(blocking() for _ in range(5))
-        reps_p = sorted(pipelined() for _ in range(5))
-        dt = reps_b[2]
+        reps_b = sorted(blocking() for _ in range(reps))
+        reps_p = sorted(pipelined() for _ in range(reps))
+        dt = reps_b[reps // 2]
         entry = {"value": calls * n_bases / dt / 1e6, "unit": "Mbp/s", "ms_per_call": dt / calls * 1e3,
                  "repetitions_Mbp_per_s": [calls * n_bases / x / 1e6 for x in reps_b],
                  "link_bytes_per_call": link_bytes[kind], "link_GBps": link_bytes[kind] * calls / dt / 1e9,
                  "link_frac_of_pcie5_x16": link_bytes[kind] * calls / dt / 1e9 / PCIE_PEAK_GBS,
                  "decisions_match_gpu": ok}
-        dt = reps_p[2]
+        dt = reps_p[reps // 2]
         entry["two_in_flight"] = {"value": calls * n_bases / dt / 1e6, "unit": "Mbp/s", "ms_per_call": dt / calls * 1e3,
                                   "repetitions_Mbp_per_s": [calls * n_bases / x / 1e6 for x in reps_p],
                                   "link_GBps": link_bytes[kind] * calls / dt / 1e9}
+        if world > 1:  # every rank measured at the same time: per rank, and the node's sum
+            for e_ in (entry, entry["two_in_flight"]):
+                e_["per_rank_Mbp_per_s"] = over_ranks(e_["value"])
+                e_["sum_over_ranks_Mbp_per_s"] = float(sum(e_["per_rank_Mbp_per_s"]))
+            entry["decisions_match_gpu_all_ranks"] = bool(min(over_ranks(1.0 if ok else 0.0)) == 1.0)
         out[kind] = entry
         log(f"host_path.{kind}: {entry['value'] / 1e3:.1f} Gbp/s blocking, {entry['two_in_flight']['value'] / 1e3:.1f} Gbp/s with two in flight, "
-            f"oracle sample ok={ok}")
+            f"check ok={ok}" + (f"; node sum {entry['two_in_flight']['sum_over_ranks_Mbp_per_s'] / 1e3:.1f} Gbp/s over {world} ranks" if world > 1 else ""))
     proc.close()
     return out
 
@@ -587,6 +647,12 @@ def main():
     # rehearsal of the N > 1 path on a one-GPU box (profiles/rehearse_two_ranks.sh): every rank on GPU 0, collectives
     # on gloo (RCCL does not take two ranks on one device).  The driver's scaling run uses neither variable.
     backend = os.environ.get("DCN_BENCH_BACKEND", "nccl")
+    # N > 1: this rank's host threads (the library's packers, result copies, torch) go to the cores next to its GPU, before
+    # anything touches the GPU or starts a thread pool -- eight ranks share one host's memory and PCIe root complexes
+    binding = None
+    if world > 1 and not os.environ.get("DCN_BENCH_NO_BIND"):
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        binding = dcn.distributed.bind_rank_to_gpu_cpus(local_rank, lw, gpu_of_rank=[0] * lw if os.environ.get("DCN_BENCH_SINGLE_DEVICE") else None)
     if os.environ.get("DCN_BENCH_SINGLE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -601,7 +667,7 @@ def main():
 
     # ---- index: host-genome minimizers + mix64 keys, identical on every rank ------------------------------------
     genome_dev = make_host_genome(args.host_genome, 3, device)
-    index, keys, host_keys, n_rand, index_build_s = build_index(genome_dev, args.index_keys, local_rank)
+    index, keys, host_keys, n_rand, index_build_s = build_index(genome_dev, args.index_keys, local_rank, world, rank)
 
     # ---- reads: resident in HBM before the timed region -----------------------------------------------------------
     P_SHORT = {"abs": 2, "rel": 0.01, "deplete": False}
@@ -614,10 +680,33 @@ def main():
 
     head, counters, elapsed, bases_done = run_device_workload(index, batches, params, args.steps, args.warmup, world, device,
                                                               reserve_long=args.workload == "long", coll_device=coll_device)
+    # what the job's one collective delivered, checked against an independent sum of what every rank put in
+    t_exp = torch.tensor([bases_done], dtype=torch.int64, device=coll_device)
+    if world > 1:
+        dist.all_reduce(t_exp, op=dist.ReduceOp.SUM)
+    collective = {"op": "all_reduce(SUM) of the six ProcessingStats counters (u64), once, inside the timed region",
+                  "backend": (str(dist.get_backend()) + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+                  "world_size": dist.get_world_size() if world > 1 else 1,
+                  "total_bp_all_reduced": int(counters["total_bp"]), "total_bp_expected": int(t_exp.item()),
+                  "total_bp_matches": int(counters["total_bp"]) == int(t_exp.item()),
+                  "cpu_binding": binding}
+    if world > 1:  # every rank's binding, for the record: number of CPUs each rank's host threads may use
+        t_b = torch.zeros(world, dtype=torch.int64, device=coll_device)
+        t_b[rank] = len((binding or {}).get("cpus") or os.sched_getaffinity(0))
+        dist.all_reduce(t_b, op=dist.ReduceOp.SUM)
+        collective["cpus_per_rank"] = [int(x) for x in t_b.cpu().tolist()]
+    # N > 1: the PCIe-inclusive legs on every rank at the same time (8 ranks share one host: the part of the path that can
+    # fail to scale), after the contract's timed region
+    host_path_all = None
+    if world > 1 and not args.no_extras and args.workload == "short":
+        try:
+            host_path_all = run_host_path(index, batches, params, None, host_cores(), calls=4, reads_per_call=args.reads,
+                                          kinds=("pinned", "packed"), reps=3, world=world, rank=rank, coll_device=coll_device)
+        except Exception as ex:  # every rank fails or none does (same code, same sizes); never take the line with it
+            log(f"host_path at N = {world} failed: {ex!r}")
+            host_path_all = {"error": repr(ex)}
     if rank == 0:
         total_bp = counters["total_bp"]
-        if args.workload != "long" or world == 1:  # long reads: every rank draws its own lengths
-            assert total_bp == bases_done * world, (total_bp, bases_done, world)
         traffic = None  # HBM bytes per scan launch from the committed PMC passes (same workload only)
         for name in ("r02_traffic.json", "r01_traffic.json"):
             try:
@@ -637,6 +726,28 @@ def main():
             rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
         except Exception as ex:
             log(f"probe-only measurement failed: {ex!r}")
+        try:
+            # ONE bound the kernel cannot exceed: the same table serving the same key stream -- batch 0's own
+            # minimizer hashes, in the kernel's order -- to a kernel that does nothing but issue the home-group reads
+            # (dcn_index_probe_ceiling: best of six launch shapes).  Beside it, the same for uniformly random groups (no
+            # reuse at all: every request an L2 miss), which is what the documented 46 G/s stands for.
+            t_c = time.time()
+            rf["probe_ceiling_random_per_s"] = index.probe_ceiling(None, 1 << 27, reps=3)
+            if args.workload == "short":
+                b0 = batches[0]
+                pc = dcn.FilterProcessor(index, max_batch_bases=b0.n_bases, max_batch_reads=b0.n_reads)
+                _, hs, _ = pc.minimizer_hashes_batch(b0.d_bases.cpu().numpy(), b0.d_offsets.cpu().numpy().astype(np.uint64))
+                pc.close()
+                d_h = torch.from_numpy(hs.view(np.int64)).to(device)
+                rf["probe_ceiling_replay_per_s"] = index.probe_ceiling(d_h.data_ptr(), d_h.numel(), reps=3)
+                rf["probe_ceiling_replay_stream"] = f"the {d_h.numel():,} valid minimizer hashes of batch 0, in read order"
+                rf["frac_of_probe_ceiling"] = rf["scattered_probes_per_s"] / rf["probe_ceiling_replay_per_s"]
+                del d_h, hs
+            log(f"probe ceiling: random {rf['probe_ceiling_random_per_s'] / 1e9:.1f} G/s, replay of batch 0's hashes "
+                f"{rf.get('probe_ceiling_replay_per_s', 0) / 1e9:.1f} G/s; the scan kernel sustains {rf['scattered_probes_per_s'] / 1e9:.1f} G/s "
+                f"({time.time() - t_c:.1f} s)")
+        except Exception as ex:
+            log(f"probe ceiling measurement failed: {ex!r}")
         if traffic:
             # measured HBM traffic (PMC) over the live launch time: what the probe kernel really pulls from HBM
             rf["traffic_rate_GBps"] = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9
@@ -664,7 +775,10 @@ def main():
             "kept_fraction": head["kept_fraction"],
             "decisions_only": head["decisions_only"],
             "index_build_s": index_build_s,
+            "collective": collective,
         }
+        if host_path_all:
+            out["host_path"] = host_path_all
         extras = [] if (args.no_extras or world > 1) else [e for e in args.extras.split(",") if e]
         oidx, cores = None, host_cores()
         need_oracle = (not args.no_cpu_baseline and world == 1) or any(e in extras for e in ("long", "paired", "host_path"))
@@ -706,8 +820,8 @@ def main():
                         f"scan {r['stage_ms_per_launch']['scan']:.2f} ms, distinct {r['stage_ms_per_launch']['distinct']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")
                 elif e == "host_path":
                     if short_batches is None:
-                        short_batches = make_batches("short", genome_dev, 2_000_000, seeds["short"], device)
-                    host_path = run_host_path(index, short_batches, P_SHORT, oidx, cores)
+                        short_batches = make_batches("short", genome_dev, args.reads, seeds["short"], device)
+                    host_path = run_host_path(index, short_batches, P_SHORT, oidx, cores, reads_per_call=args.reads)
                 elif e == "cli":
                     # `deacon-hip` file to file, as a user runs it (bench_cli.py): configs[0] at its stated shape, then
                     # search / host depletion / two files of mates against this index written as an index FILE
@@ -743,7 +857,7 @@ def main():
                 if e == "host1g":
                     # sensitivity point: a >= 1 Gbp host genome (a real 3 Gbp host leaves far fewer of a batch's probes in cache)
                     g2 = make_host_genome(1_000_000_000, 13, device)
-                    idx2, keys2, hk2, nr2, _ = build_index(g2, args.index_keys, local_rank)
+                    idx2, keys2, hk2, nr2, _ = build_index(g2, args.index_keys, local_rank)  # (extras run at world == 1 only)
                     del keys2
                     bs = make_batches("short", g2, args.reads, 15, device)
                     r, _, _, _ = run_device_workload(idx2, bs, P_SHORT, 12, 3, 1, device)

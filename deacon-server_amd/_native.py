@@ -79,6 +79,7 @@ _SIGNATURES = {
     "dcn_index_header": (C.c_int, [_vp, _u8p, _u8p, _u64p]),
     "dcn_index_contains": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "dcn_index_contains_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp, _vp]),
+    "dcn_index_probe_ceiling": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
     "dcn_index_destroy": (None, [_vp]),
     "dcn_ctx_create": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
     "dcn_ctx_destroy": (None, [_vp]),

@@ -261,6 +261,12 @@ extern "C" int dcn_index_contains_device(const dcn_index *index, const uint64_t 
     return dcn_table_contains_device(index, d_keys, n, d_out, (hipStream_t)stream);
 }
 
+extern "C" int dcn_index_probe_ceiling(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint32_t reps,
+                                       double *probes_per_s) {
+    if (!index || !probes_per_s) return dcn_fail(DCN_ERR_ARG, "index/probes_per_s is NULL");
+    return dcn_table_probe_ceiling(index, d_keys, n, reps, probes_per_s, nullptr);
+}
+
 extern "C" int dcn_index_clone(const dcn_index *index, int device, dcn_index **out) {
     if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
     *out = nullptr;

@@ -180,6 +180,8 @@ int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);
 int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t n, uint8_t *out);
 int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
                               hipStream_t stream);
+int dcn_table_probe_ceiling(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint32_t reps, double *best,
+                            hipStream_t stream);
 int dcn_table_insert_varint9(dcn_index *idx, const uint64_t *d_raw, uint64_t n, unsigned long long *d_new,
                              uint32_t *d_zero, uint32_t *d_bad, hipStream_t stream); // 9-byte varint records
 uint64_t dcn_table_groups_for(uint64_t n_keys);                                  // sizing rule (see DCN_SLOTS_PER_KEY)

@@ -220,6 +220,88 @@ int dcn_table_contains(const dcn_index *idx, const uint64_t *host_keys, uint64_t
     return rc;
 }
 
+// ---- the measured ceiling of the probe stage --------------------------------------------------------------------------
+// Nothing but the home-group read of every key (one 16-byte request each), U of them in flight per lane, the results
+// folded into a register: what the memory system gives THIS table for THIS key stream when no other work competes.
+// d_keys == null: pseudo-random keys made in the kernel (uniform over the table: every probe an L2 miss).
+namespace {
+__device__ inline uint64_t probe_mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void probe_ceiling_kernel(dcn_table_view t, const uint64_t *keys, uint64_t n, uint64_t salt,
+                                                            uint64_t *sink) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t acc = 0;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+        uint64_t key[U];
+        u64x2 g[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t i = i0 + u * stride;
+            key[u] = keys ? (i < n ? keys[i] : 0) : probe_mix64(i + salt);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t grp = dcn_group_of(key[u], t.group_shift, t.group_mask);
+            const u64x2 *p = reinterpret_cast<const u64x2 *>(t.slots + (uint64_t)grp * DCN_GROUP_SLOTS);
+            g[u] = (i0 + u * stride < n) ? (NT ? __builtin_nontemporal_load(p) : *p) : u64x2{0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += g[u].x ^ g[u].y ^ key[u];
+    }
+    if (acc == 0x123456789ABCDEFull) sink[0] = acc; // keeps the loads alive
+}
+
+template <int U, bool NT>
+int time_probe_ceiling(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint32_t reps, uint32_t blocks,
+                       uint64_t *d_sink, hipStream_t stream, double *rate) {
+    hipEvent_t a, b;
+    DCN_HIP(hipEventCreate(&a));
+    DCN_HIP(hipEventCreate(&b));
+    hipLaunchKernelGGL((probe_ceiling_kernel<U, NT>), dim3(blocks), dim3(256), 0, stream, idx->view(), d_keys, n, 1ull, d_sink);
+    DCN_HIP(hipEventRecord(a, stream));
+    for (uint32_t r = 0; r < reps; ++r)  // another salt per repetition: a generated stream never re-probes the lines of the last one
+        hipLaunchKernelGGL((probe_ceiling_kernel<U, NT>), dim3(blocks), dim3(256), 0, stream, idx->view(), d_keys, n,
+                           0x9E3779B97F4A7C15ull * (r + 2), d_sink);
+    DCN_HIP(hipEventRecord(b, stream));
+    DCN_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    DCN_HIP(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    DCN_HIP(hipGetLastError());
+    *rate = ms > 0 ? (double)n * reps / (ms * 1e-3) : 0.0;
+    return DCN_OK;
+}
+} // namespace
+
+int dcn_table_probe_ceiling(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint32_t reps, double *best,
+                            hipStream_t stream) {
+    DCN_HIP(hipSetDevice(idx->device));
+    *best = 0;
+    if (n == 0 || reps == 0) return DCN_OK;
+    uint64_t *d_sink = nullptr;
+    DCN_HIP(hipMalloc(&d_sink, sizeof(uint64_t)));
+    double r[6] = {0, 0, 0, 0, 0, 0};
+    int rc = DCN_OK;
+    // the forms the microbenchmarks found within a few per cent of each other (profiles/microbench/probe_patterns.hip): the
+    // best of them is the ceiling
+    const uint32_t wide = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 32), narrow = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 8);
+    if (rc == DCN_OK) rc = time_probe_ceiling<4, false>(idx, d_keys, n, reps, wide, d_sink, stream, &r[0]);
+    if (rc == DCN_OK) rc = time_probe_ceiling<4, true>(idx, d_keys, n, reps, wide, d_sink, stream, &r[1]);
+    if (rc == DCN_OK) rc = time_probe_ceiling<1, false>(idx, d_keys, n, reps, wide, d_sink, stream, &r[2]);
+    if (rc == DCN_OK) rc = time_probe_ceiling<1, true>(idx, d_keys, n, reps, wide, d_sink, stream, &r[3]);
+    if (rc == DCN_OK) rc = time_probe_ceiling<8, false>(idx, d_keys, n, reps, narrow, d_sink, stream, &r[4]);
+    if (rc == DCN_OK) rc = time_probe_ceiling<8, true>(idx, d_keys, n, reps, narrow, d_sink, stream, &r[5]);
+    hipFree(d_sink);
+    for (double x : r) *best = std::max(*best, x);
+    return rc;
+}
+
 int dcn_table_contains_device(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
                               hipStream_t stream) {
     DCN_HIP(hipSetDevice(idx->device));

@@ -55,3 +55,81 @@ def gather_keep_in_order(local_batches, n_units, batch_units, group=None, device
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)  # every unit is written by exactly one rank
         keep = t.cpu().numpy()
     return keep.astype(bool)
+
+
+# ---- host threads next to the rank's GPU ------------------------------------------------------------------------------
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_topology(sysfs="/sys"):
+    """[(numa_node, [cpus])] per GPU in HIP ordinal order, read from sysfs only (no GPU call: the affinity has to be
+    set before the runtime and the library's host threads exist).  KFD lists its nodes in the order HIP enumerates
+    them; the ones with SIMDs are GPUs, and `drm_render_minor` names each one's DRM device, whose `numa_node` /
+    `local_cpulist` say which cores sit on its socket."""
+    import glob
+    import os
+    import re
+    gpus = []
+    nodes = sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*")), key=lambda p: int(os.path.basename(p)))
+    for nd in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(nd, "properties")).read().splitlines() if " " in line)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) == 0:
+            continue
+        dev = os.path.join(sysfs, "class/drm", "renderD%d" % int(props.get("drm_render_minor", "-1")), "device")
+        try:
+            numa = int(open(os.path.join(dev, "numa_node")).read())
+            cpus = parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        except (OSError, ValueError):
+            numa, cpus = -1, []
+        gpus.append((numa, cpus))
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    if vis and re.fullmatch(r"[0-9]+(,[0-9]+)*", vis):  # ordinals are positions in the visible list
+        gpus = [gpus[int(i)] for i in vis.split(",") if int(i) < len(gpus)]
+    return gpus
+
+
+def cpus_for_rank(local_rank, local_world, allowed, topology, gpu_of_rank=None):
+    """CPUs this rank's host threads should run on: the allowed CPUs local to its GPU, shared out evenly between the
+    ranks whose GPUs sit on the same NUMA node (counterpart of the reference's one reader feeding N workers,
+    src/local_filter.rs:696-709: here every rank has its own packer threads, and 8 of them share one host).
+    gpu_of_rank: GPU ordinal of every local rank (default: rank r drives GPU r; a rehearsal puts all ranks on GPU 0).
+    Returns (cpus, note); cpus is None when there is nothing sensible to bind to."""
+    allowed = sorted(allowed)
+    gpu_of_rank = list(range(local_world)) if gpu_of_rank is None else list(gpu_of_rank)
+    gpu = gpu_of_rank[local_rank] if local_rank < len(gpu_of_rank) else local_rank
+    if gpu >= len(topology):
+        return None, f"GPU {gpu} not found in the KFD topology ({len(topology)} GPUs listed)"
+    numa, local = topology[gpu]
+    near = [c for c in local if c in set(allowed)]
+    if not near:
+        return None, f"no allowed CPU is local to GPU {gpu} (NUMA node {numa})"
+    peers = [r for r in range(len(gpu_of_rank)) if gpu_of_rank[r] < len(topology) and topology[gpu_of_rank[r]][0] == numa]
+    i, n = peers.index(local_rank), len(peers)
+    share = near[len(near) * i // n:len(near) * (i + 1) // n]
+    if not share:
+        return None, f"fewer allowed CPUs ({len(near)}) than ranks ({n}) on NUMA node {numa}"
+    return share, f"NUMA node {numa}: {len(share)} of its {len(near)} allowed CPUs (rank {i + 1} of {n} on that node)"
+
+
+def bind_rank_to_gpu_cpus(local_rank, local_world, sysfs="/sys", gpu_of_rank=None):
+    """sched_setaffinity of the calling process (threads created later inherit it).  Call before any GPU call."""
+    import os
+    try:
+        topo = gpu_numa_topology(sysfs)
+        cpus, note = cpus_for_rank(local_rank, local_world, os.sched_getaffinity(0), topo, gpu_of_rank)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"cpus": cpus, "note": note}
+    except Exception as ex:  # never fatal: an unbound rank is slower, not wrong
+        return {"cpus": None, "note": f"not bound: {ex!r}"}

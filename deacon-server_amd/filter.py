@@ -206,6 +206,13 @@ class Index:
         """Device-resident probe: d_keys / d_out are raw device pointers; asynchronous on `stream`."""
         N.check(N.lib().dcn_index_contains_device(self._h, d_keys, n, d_out, stream))
 
+    def probe_ceiling(self, d_keys=None, n=64_000_000, reps=5):
+        """Home-group reads per second this table serves for a key stream (device pointer; None: uniformly random
+        groups) with nothing else running -- dcn_index_probe_ceiling."""
+        r = C.c_double()
+        N.check(N.lib().dcn_index_probe_ceiling(self._h, d_keys, n, reps, C.byref(r)))
+        return r.value
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib().dcn_index_destroy(self._h)

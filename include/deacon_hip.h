@@ -134,6 +134,15 @@ int dcn_index_contains(const dcn_index *index, const uint64_t *keys, uint64_t n,
 int dcn_index_contains_device(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint8_t *d_out,
                               void *stream);
 
+/* Measurement: the rate (home-group reads per second) at which this table serves a stream of keys when nothing else
+ * runs -- every key's home group is read (one 16-byte request), nothing is resolved or written; the best of several
+ * launch shapes over `reps` repetitions.  d_keys (DEVICE pointer) is the stream to replay, e.g. a batch's minimizer
+ * hashes; NULL probes n uniformly random groups instead (every request an L2 miss).  This is the ceiling the probe
+ * stage of the filter kernel is measured against (bench.py: roofline.probe_ceiling_*; the counterpart of timing
+ * FxHashSet::contains alone, src/filter_common.rs:144).  Blocks until done. */
+int dcn_index_probe_ceiling(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint32_t reps,
+                            double *probes_per_s);
+
 /* Replica of an index on another (or the same) device, copied device to device (hipMemcpyPeer over xGMI): the
  * reference shares ONE set between its workers through an Arc (src/local_filter.rs:630-631); a multi-GPU host
  * loads or builds the index once and clones it to every other device instead of repeating the host-to-device copy. */

@@ -54,3 +54,55 @@ def test_two_ranks_with_the_gpu_engine(tmp_path):
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     res = json.load(open(out))
     assert res["world"] == 2 and res["stats"] == res["want"] and res["keep_equal"]
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: [(numa, cpulist text)] -> a sysfs tree with one CPU-only KFD node followed by the GPU nodes"""
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 96\nsimd_count 0\ndrm_render_minor 0\n")
+    for i, (numa, cpus) in enumerate(gpus):
+        (nodes / str(i + 1)).mkdir()
+        (nodes / str(i + 1) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + i}\n")
+        dev = root / "class/drm" / f"renderD{128 + i}" / "device"
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{numa}\n")
+        (dev / "local_cpulist").write_text(cpus + "\n")
+    return str(root)
+
+
+def test_ranks_are_bound_to_the_cpus_next_to_their_gpu(dcn, tmp_path, monkeypatch):
+    """bench.py's N > 1 runs share one host: each rank's host threads (packers, result copies) go to the cores of its
+    GPU's socket, split between the ranks of that socket (sysfs only -- no GPU call before the binding)."""
+    D = dcn.distributed
+    assert D.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and D.parse_cpulist("") == []
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    sysfs = _fake_sysfs(tmp_path, [(0, "0-47,96-143")] * 4 + [(1, "48-95,144-191")] * 4)
+    topo = D.gpu_numa_topology(sysfs)
+    assert [n for n, _ in topo] == [0, 0, 0, 0, 1, 1, 1, 1] and topo[5][1][:2] == [48, 49]
+    allowed = set(range(192))
+    shares = [D.cpus_for_rank(r, 8, allowed, topo)[0] for r in range(8)]
+    assert all(len(s) == 24 for s in shares)
+    assert sorted(c for s in shares for c in s) == list(range(192))           # a partition of the host
+    assert set(shares[0]) <= set(topo[0][1]) and set(shares[7]) <= set(topo[7][1])
+    # a cgroup that only allows part of a socket: the share comes from what is allowed
+    s, note = D.cpus_for_rank(4, 8, set(range(40, 64)), topo)
+    assert s == [48, 49, 50, 51] and "NUMA node 1" in note
+    # nothing local is allowed / unknown GPU: no binding rather than a wrong one
+    assert D.cpus_for_rank(0, 8, set(range(48, 96)), topo)[0] is None
+    assert D.cpus_for_rank(9, 16, allowed, topo)[0] is None
+    # one rank on a one-GPU box keeps every allowed local core
+    one = D.gpu_numa_topology(_fake_sysfs(tmp_path / "one", [(0, "0-15")]))
+    assert D.cpus_for_rank(0, 1, set(range(8)), one)[0] == list(range(8))
+    # a rehearsal with every rank on GPU 0 (profiles/rehearse_two_ranks.sh): the ranks split GPU 0's cores
+    a, b = (D.cpus_for_rank(r, 2, set(range(16)), one, gpu_of_rank=[0, 0])[0] for r in (0, 1))
+    assert a == list(range(8)) and b == list(range(8, 16))
+    # visible-device remapping: ordinal 0 is the second physical GPU
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5,1")
+    assert [n for n, _ in D.gpu_numa_topology(sysfs)] == [1, 0]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # the real call never raises, whatever this machine's sysfs holds
+    before = os.sched_getaffinity(0)
+    r = D.bind_rank_to_gpu_cpus(0, 1, sysfs=str(tmp_path / "absent"))
+    assert r["cpus"] is None and os.sched_getaffinity(0) == before

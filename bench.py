@@ -236,6 +236,44 @@ def make_long_reads(genome_dev, total_bases, seed, device, host_frac=0.5, sub=0.
     return out, torch.from_numpy(offsets).to(device)
 
 
+def make_mixed_reads(genome_dev, total_bases, seed, device):
+    """BASELINE configs[4]'s stream shape: half of the bases in ONT-style long reads (as configs[2]),
+    half in 150 bp reads (as configs[1]), interleaved in one stream -- every long read is followed by as many short reads as
+    it has bases / 150.  Returns (bases u8[], offsets int64[n+1])."""
+    lb, lo = make_long_reads(genome_dev, total_bases // 2, seed, device)
+    lo_np = lo.cpu().numpy()
+    llen = np.diff(lo_np)
+    n_short_after = np.maximum(1, np.rint(llen / READ_LEN).astype(np.int64))
+    n_short = int(n_short_after.sum())
+    sb = make_reads(genome_dev, n_short, seed + 1, device)
+    # lengths in stream order: long_0, short x c_0, long_1, short x c_1, ...
+    n_long = len(llen)
+    pos_long = np.arange(n_long) + np.concatenate([[0], np.cumsum(n_short_after)[:-1]])  # index of long read i in the stream
+    n_all = n_long + n_short
+    lens = np.full(n_all, READ_LEN, np.int64)
+    lens[pos_long] = llen
+    offsets = np.zeros(n_all + 1, np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    is_long = np.zeros(n_all, bool)
+    is_long[pos_long] = True
+    out = torch.empty(int(offsets[-1]), dtype=torch.uint8, device=device)
+    # long reads: out[dest_start_i + j] = lb[lo_i + j]; short reads likewise from the (n_short, 150) block -- copied in
+    # slices of <= 64 M bases of source
+    def scatter(src, src_off, dst_off):
+        a = 0
+        while a < len(src_off) - 1:
+            b = int(np.searchsorted(src_off, src_off[a] + (1 << 26), side="right")) - 1
+            b = min(max(b, a + 1), len(src_off) - 1)
+            ln = torch.from_numpy(np.diff(src_off[a:b + 1])).to(device)
+            shift = torch.from_numpy(dst_off[a:b] - src_off[a:b]).to(device)
+            idx = torch.arange(int(src_off[a]), int(src_off[b]), device=device)
+            out[idx + torch.repeat_interleave(shift, ln)] = src[int(src_off[a]):int(src_off[b])]
+            a = b
+    scatter(lb, lo_np, offsets[:-1][is_long])
+    scatter(sb, np.arange(n_short + 1, dtype=np.int64) * READ_LEN, offsets[:-1][~is_long])
+    return out, torch.from_numpy(offsets).to(device)
+
+
 class Batch:
     """one batch resident in HBM: ASCII + offsets (+ unit ids) and its result arrays"""
 
@@ -264,6 +302,9 @@ def make_batches(kind, genome_dev, reads, seed, device, rotate=ROTATE, host_frac
                              (torch.arange(n, dtype=torch.int32, device=device) // 2).contiguous()))
         elif kind == "long":
             b, o = make_long_reads(genome_dev, reads * READ_LEN, seed + 100 * i, device)
+            out.append(Batch(b, o))
+        elif kind == "mixed":
+            b, o = make_mixed_reads(genome_dev, reads * READ_LEN, seed + 100 * i, device)
             out.append(Batch(b, o))
         else:
             raise ValueError(kind)
@@ -627,9 +668,10 @@ def main():
     ap.add_argument("--index-keys", type=int, default=PANHUMAN_KEYS)
     ap.add_argument("--host-genome", type=int, default=64_000_000,
                     help="bases of the synthetic host genome (SURVEY.md 8d config 2: 64 Mbp, ~8 M of the index keys)")
-    ap.add_argument("--workload", choices=["short", "paired", "long"], default="short",
+    ap.add_argument("--workload", choices=["short", "paired", "long", "mixed"], default="short",
                     help="the workload `value` is measured on.  short: configs[1] 150 bp single reads (the headline); "
-                         "paired: configs[3] 2x150 bp --deplete; long: configs[2] ONT-style lognormal reads, mean 10 kbp")
+                         "paired: configs[3] 2x150 bp --deplete; long: configs[2] ONT-style lognormal reads, mean 10 kbp; "
+                         "mixed: configs[4]'s stream, half of the bases long and half short in one batch, --deplete")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other configs and the host-path measurements that follow the headline at N = 1")
@@ -672,14 +714,14 @@ def main():
     # ---- reads: resident in HBM before the timed region -----------------------------------------------------------
     P_SHORT = {"abs": 2, "rel": 0.01, "deplete": False}
     P_PAIRED = {"abs": 2, "rel": 0.01, "deplete": True}
-    params = P_PAIRED if args.workload == "paired" else P_SHORT
-    seeds = {"short": 5, "long": 6, "paired": 7}
+    params = P_PAIRED if args.workload in ("paired", "mixed") else P_SHORT
+    seeds = {"short": 5, "long": 6, "paired": 7, "mixed": 9}
     batches = make_batches(args.workload, genome_dev, args.reads, seeds[args.workload] + 1000 * rank, device)
     torch.cuda.synchronize()
     log(f"{args.workload}: {len(batches)} batches of {batches[0].n_reads:,} reads / {batches[0].n_bases / 1e6:.0f} Mbp resident in HBM")
 
     head, counters, elapsed, bases_done = run_device_workload(index, batches, params, args.steps, args.warmup, world, device,
-                                                              reserve_long=args.workload == "long", coll_device=coll_device)
+                                                              reserve_long=args.workload in ("long", "mixed"), coll_device=coll_device)
     # what the job's one collective delivered, checked against an independent sum of what every rank put in
     t_exp = torch.tensor([bases_done], dtype=torch.int64, device=coll_device)
     if world > 1:
@@ -689,7 +731,7 @@ def main():
                   "world_size": dist.get_world_size() if world > 1 else 1,
                   "total_bp_all_reduced": int(counters["total_bp"]), "total_bp_expected": int(t_exp.item()),
                   "total_bp_matches": int(counters["total_bp"]) == int(t_exp.item()),
-                  "cpu_binding": binding}
+                  "cpu_binding": {k_: v for k_, v in binding.items() if k_ != "cpus"} if binding else None}
     if world > 1:  # every rank's binding, for the record: number of CPUs each rank's host threads may use
         t_b = torch.zeros(world, dtype=torch.int64, device=coll_device)
         t_b[rank] = len((binding or {}).get("cpus") or os.sched_getaffinity(0))
@@ -754,7 +796,8 @@ def main():
             rf["traffic_frac_of_peak"] = rf["traffic_rate_GBps"] / HBM_PEAK_GBS
         names = {"short": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
                  "paired": "configs[3]: paired 2x150 bp --deplete vs panhuman-1-sized index, inputs resident in HBM as ASCII",
-                 "long": "configs[2]: ONT-style lognormal reads (mean 10 kbp) vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII"}
+                 "long": "configs[2]: ONT-style lognormal reads (mean 10 kbp) vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
+                 "mixed": "configs[4]'s stream shape: half of the bases in ONT-style long reads, half in 150 bp reads, interleaved, --deplete, inputs resident in HBM as ASCII"}
         out = {
             "metric": "Mbp/s filtered (k=31,w=15 vs panhuman-1-sized index), decisions bit-exact vs CPU",
             "value": head["value"], "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -899,19 +942,24 @@ def main():
                     index.close()
                     idx3, keys3, hk3, nr3, tb = build_index(genome_dev, UNION_KEYS, local_rank)
                     del keys3
-                    bs = make_batches("paired", genome_dev, args.reads, 27, device)
-                    r, _, _, _ = run_device_workload(idx3, bs, P_PAIRED, 12, 3, 1, device)
-                    b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
-                    small = touchable_oracle_index(b_, o_, hk3, nr3, cores)
-                    keep, hits, total = oracle_decisions(small, b_, o_, u_, P_PAIRED, cores)
-                    ok = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
-                        bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all())
-                    r["decisions_match_gpu"] = ok
-                    r["oracle_sample"] = (f"first {len(o_) - 1} reads of batch 0 vs the oracle on the {len(small):,} index keys the sample "
-                                          "can touch (membership of the mix64 remainder decided from its definition)")
-                    r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB), paired 2x150 bp --deplete"
-                    r["table_build_s"] = tb
-                    workloads["union950m"] = r
+                    for key_, kind_, seed_ in (("union950m", "mixed", 29), ("union950m_paired", "paired", 27)):
+                        bs = make_batches(kind_, genome_dev, args.reads, seed_, device)
+                        r, _, _, _ = run_device_workload(idx3, bs, P_PAIRED, 12, 3, 1, device, reserve_long=kind_ == "mixed")
+                        b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
+                        small = touchable_oracle_index(b_, o_, hk3, nr3, cores)
+                        keep, hits, total = oracle_decisions(small, b_, o_, u_, P_PAIRED, cores)
+                        ok = bool((bs[0].d_keep[:nu_].cpu().numpy().astype(bool) == keep).all()) and \
+                            bool((bs[0].d_hits[:nu_].cpu().numpy() == hits).all())
+                        r["decisions_match_gpu"] = ok
+                        r["oracle_sample"] = (f"first {len(o_) - 1} reads of batch 0 vs the oracle on the {len(small):,} index keys the sample "
+                                              "can touch (membership of the mix64 remainder decided from its definition)")
+                        shape = ("configs[4]'s stream: half of the bases in ONT-style long reads (lognormal, mean 10 kbp), half in 150 bp "
+                                 "reads, interleaved in one batch, --deplete" if kind_ == "mixed" else "paired 2x150 bp --deplete")
+                        r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB); {shape}"
+                        r["table_build_s"] = tb
+                        workloads[key_] = r
+                        del bs
+                    r = workloads["union950m"]
                     idx3.close()
                     index = None
                     log(f"workloads.union950m: {r['value'] / 1e3:.1f} Gbp/s counting, scan {r['stage_ms_per_launch']['scan']:.2f} ms, oracle ok={ok} ({time.time() - t_e:.0f} s)")

@@ -92,7 +92,8 @@ struct WaveShared {
                   // 4 = no list store, 8 = no duplicate compare, 16 = no mask loads,
                   // 64 = k / l streams reuse the in-stream words (2 instead of 6 stream loads per block),
                   // 128 = no stream loads at all in the main loop (words recycled), 256 = hits of units the wave does not
-                  // finish are not written to their runs
+                  // finish are not written to their runs, 512 = their bookkeeping runs but the store itself is left out,
+                  // 1024 = such units are not enrolled for the distinct pass (no tile_hits store, no atomics at the wave's end)
 #endif
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         any_rec = true;
                         if (rec) {
                             const uint32_t before = sh.uhits[o_uslot[u]];
-                            a.rec_hash[sh.run_base[o_uslot[u]] + before + rank] = hash[u];
+                            if (!(DCN_EXP & 512)) a.rec_hash[sh.run_base[o_uslot[u]] + before + rank] = hash[u];
                             if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
                         if (run_head) { // after every lane of the run has read the old length: one update per run
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     // ---- units left to the distinct pass: run lengths, hit totals, enrolment ------------------------------------------
     if (any_rec && lane == 0) a.status->any_records = 1;
     {
-        const bool pending = have_tile && !sh.lok[uslot];
+        const bool pending = have_tile && !sh.lok[uslot] && !(DCN_EXP & 1024);
         bool enrol = false;
         if (pending) {
             const uint32_t th = head ? sh.uhits[uslot] : 0u; // the run hangs on the unit's first tile in this wave

@@ -69,6 +69,19 @@ def parse_cpulist(text):
     return out
 
 
+def format_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11'"""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
 def gpu_numa_topology(sysfs="/sys"):
     """[(numa_node, [cpus])] per GPU in HIP ordinal order, read from sysfs only (no GPU call: the affinity has to be
     set before the runtime and the library's host threads exist).  KFD lists its nodes in the order HIP enumerates
@@ -130,6 +143,6 @@ def bind_rank_to_gpu_cpus(local_rank, local_world, sysfs="/sys", gpu_of_rank=Non
         cpus, note = cpus_for_rank(local_rank, local_world, os.sched_getaffinity(0), topo, gpu_of_rank)
         if cpus:
             os.sched_setaffinity(0, cpus)
-        return {"cpus": cpus, "note": note}
+        return {"cpus": cpus, "cpulist": format_cpulist(cpus) if cpus else None, "note": note}
     except Exception as ex:  # never fatal: an unbound rank is slower, not wrong
-        return {"cpus": None, "note": f"not bound: {ex!r}"}
+        return {"cpus": None, "cpulist": None, "note": f"not bound: {ex!r}"}

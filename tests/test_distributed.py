@@ -76,6 +76,7 @@ def test_ranks_are_bound_to_the_cpus_next_to_their_gpu(dcn, tmp_path, monkeypatc
     GPU's socket, split between the ranks of that socket (sysfs only -- no GPU call before the binding)."""
     D = dcn.distributed
     assert D.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and D.parse_cpulist("") == []
+    assert D.format_cpulist([11, 0, 1, 2, 3, 8, 10]) == "0-3,8,10-11" and D.format_cpulist([]) == ""
     monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
     monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
     sysfs = _fake_sysfs(tmp_path, [(0, "0-47,96-143")] * 4 + [(1, "48-95,144-191")] * 4)

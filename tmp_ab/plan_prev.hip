@@ -37,20 +37,13 @@ __device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32
 // count).  A unit cut by a workgroup boundary is marked non-contiguous.
 // PLAN_CH = reads per thread: 8 for batches of many short reads (few cursor atomics), 1 when reads are few / long
 // (more workgroups, and the per-workgroup loop over long reads stays short).
-//
-// Two classes inside a workgroup's range (batches without unit ids, where a read is a unit): first the tiles of the
-// reads that need several tiles, then the single-tile reads.  A stream that mixes long and short reads (BASELINE
-// configs[4]) otherwise puts both kinds into most scan waves: the short reads' lanes idle through 60 % of the wave's
-// steps, and -- worse -- the mid-scan flush a long tile forces takes the in-wave resolution away from every short read
-// of the wave, whose hits then all go through the distinct pass (measured: 157 Gbp/s against 250 / 380 Gbp/s for the
-// long / short reads alone).  Reads keep their order inside a class, and a read's tiles stay consecutive.
 template <uint32_t PLAN_CH>
 __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     constexpr uint32_t PLAN_READS = 256 * PLAN_CH;
     constexpr uint32_t OWN = 4; // tiles a thread writes itself; longer reads are finished by the whole workgroup
     __shared__ uint32_t s_tiles[PLAN_READS];
     __shared__ uint32_t s_first[PLAN_READS];
-    __shared__ uint32_t s_wave[4], s_wave1[4];
+    __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_base;
     __shared__ uint32_t long_reads[PLAN_READS];
     __shared__ uint32_t n_long;
@@ -62,9 +55,7 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     // (a.ascii == null) or when the pack kernel, which reads every byte anyway, saw no '\n' at all
     const uint8_t *ascii = (a.ascii && a.status->any_newline) ? a.ascii : nullptr;
     uint32_t nwin[PLAN_CH], nt[PLAN_CH], loc[PLAN_CH];
-    const bool two_classes = a.unit_id == nullptr;
-    uint32_t carry = 0;  // tiles of the chunks before this one: all of them, or (two classes) those of multi-tile reads
-    uint32_t carry1 = 0; // two classes: single-tile reads of the chunks before this one
+    uint32_t carry = 0; // tiles of the chunks before this one
 #pragma unroll
     for (uint32_t c = 0; c < PLAN_CH; ++c) {
         const uint32_t r = block_first + c * 256 + tid;
@@ -75,46 +66,29 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
             nwin[c] = effective_windows(ascii, off, a.offsets[r + 1] - off, a.prefix_length, a.k, a.k + a.w - 1);
             nt[c] = (nwin[c] + a.tile_windows - 1) / a.tile_windows;
         }
-        const bool single = two_classes && nt[c] == 1;
-        const uint32_t own = single ? 0u : nt[c], own1 = single ? 1u : 0u;
-        uint32_t inc = own, inc1 = own1;
+        uint32_t inc = nt[c];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(inc, d, 64), o1 = __shfl_up(inc1, d, 64);
-            if ((int)(tid & 63) >= d) {
-                inc += o;
-                inc1 += o1;
-            }
+            uint32_t o = __shfl_up(inc, d, 64);
+            if ((int)(tid & 63) >= d) inc += o;
         }
         __syncthreads(); // s_wave free again
-        if ((tid & 63) == 63) {
-            s_wave[tid >> 6] = inc;
-            s_wave1[tid >> 6] = inc1;
-        }
+        if ((tid & 63) == 63) s_wave[tid >> 6] = inc;
         __syncthreads();
-        uint32_t wave_base = 0, chunk_total = 0, wave_base1 = 0, chunk_total1 = 0;
+        uint32_t wave_base = 0, chunk_total = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 4; ++i) {
-            if (i < (tid >> 6)) {
-                wave_base += s_wave[i];
-                wave_base1 += s_wave1[i];
-            }
+            if (i < (tid >> 6)) wave_base += s_wave[i];
             chunk_total += s_wave[i];
-            chunk_total1 += s_wave1[i];
         }
-        // (a single-tile read's place is counted from the start of its class here; the class's start is added below)
-        loc[c] = single ? (0x80000000u | (carry1 + wave_base1 + inc1 - 1u)) : (carry + wave_base + inc - own);
+        loc[c] = carry + wave_base + inc - nt[c];
         carry += chunk_total;
-        carry1 += chunk_total1;
         s_tiles[c * 256 + tid] = nt[c];
     }
-    if (tid == 0) s_base = (carry + carry1) ? atomicAdd(a.tile_cursor, carry + carry1) : 0u;
+    if (tid == 0) s_base = carry ? atomicAdd(a.tile_cursor, carry) : 0u;
     __syncthreads();
 #pragma unroll
-    for (uint32_t c = 0; c < PLAN_CH; ++c) {
-        if (loc[c] & 0x80000000u) loc[c] = carry + (loc[c] & 0x7FFFFFFFu); // single-tile reads follow the multi-tile ones
-        s_first[c * 256 + tid] = s_base + loc[c];
-    }
+    for (uint32_t c = 0; c < PLAN_CH; ++c) s_first[c * 256 + tid] = s_base + loc[c];
     __syncthreads();
 #pragma unroll
     for (uint32_t c = 0; c < PLAN_CH; ++c) {

@@ -418,6 +418,28 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
     return res, counters, elapsed, bases_done
 
 
+def committed_traffic(rf, workload, bases_per_batch, index_keys, host_genome):
+    """HBM bytes per scan launch from the committed PMC passes of the same workload (profiles/collect_r3.sh ->
+    profiles/make_traffic_json.py): counters cannot be read inside a timed run, so `roofline.traffic` is the per-launch
+    figure measured for this workload shape on this tree, and says where it comes from."""
+    names = {"short": ("r03_traffic.json", "r02_traffic.json"), "long": ("r03_traffic_long.json",), "mixed": ("r03_traffic_mixed.json",)}
+    for name in names.get(workload, ()):
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+            wlk = tr["workload"]
+            bases = wlk.get("bases_per_batch", wlk["reads_per_batch"] * READ_LEN)
+            if (wlk["workload"] == workload and abs(bases - bases_per_batch) <= 0.01 * bases_per_batch
+                    and wlk["index_keys"] == index_keys and wlk.get("host_genome_bases") == host_genome):
+                rf["traffic"] = tr["scan_kernel"]["hbm_bytes_per_launch"]
+                rf["traffic_source"] = "profiles/" + name
+                rf["traffic_rate_GBps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+                rf["traffic_frac_of_peak"] = rf["traffic_rate_GBps"] / HBM_PEAK_GBS
+                return rf["traffic"]
+        except Exception:
+            pass
+    return None
+
+
 def probe_only_rate(index, device, n=64_000_000, reps=5):
     """The library's own set-membership kernel (dcn_index_contains_device: one 16-byte group read per key, nothing else)
     on n uniformly random keys against the SAME table: the scattered-request rate this box gives this table now.
@@ -483,11 +505,13 @@ def check_against_oracle(oidx, batch, params, max_bases, threads, keep_dev=None)
     return ok, f"first {len(off) - 1} reads ({int(off[-1]) / 1e6:.1f} Mbp) of batch 0"
 
 
-def cpu_baseline(oidx, cores, batch, params, seconds_target=12.0):
+def cpu_baseline(oidx, cores, batch, params, seconds_target=12.0, tuned=False, port_result=None):
     """Time the CPU oracle (all host cores) on a bounded sample of the headline reads and check the GPU's decisions
-    on that sample against it."""
+    on that sample against it.  tuned: the "port-tuned" form of the same arithmetic (oracle/deacon_oracle.c,
+    dor_filter_batch_tuned_mt: one workspace per thread, two-stack window minima, epoch-tagged seen-set, rolling
+    k-mer values, units dealt in chunks) -- the leg that is not a strawman; it must equal the plain port on its sample."""
     from oracle import oracle as O
-    n_total = min(batch.n_reads, 2_000_000)
+    n_total = min(batch.n_reads, 4_000_000 if tuned else 2_000_000)
     bases_np = batch.d_bases[:n_total * READ_LEN].cpu().numpy()
 
     def run(n, repeats=1):
@@ -495,7 +519,7 @@ def cpu_baseline(oidx, cores, batch, params, seconds_target=12.0):
         t = time.time()
         for _ in range(repeats):
             res = O.filter_batch(oidx, bases_np[:n * READ_LEN], off, None, params["abs"], params["rel"], 0,
-                                 params["deplete"], threads=cores)
+                                 params["deplete"], threads=cores, tuned=tuned)
         return time.time() - t, res
 
     probe_n = min(10_000 * cores, n_total)
@@ -506,13 +530,23 @@ def cpu_baseline(oidx, cores, batch, params, seconds_target=12.0):
     dt, (keep, hits, total) = run(n, repeats)
     ok = bool((batch.d_keep[:n].cpu().numpy().astype(bool) == keep).all()) and \
         bool((batch.d_hits[:n].cpu().numpy() == hits).all())
-    return {
-        "value": n * repeats * READ_LEN / dt / 1e6, "unit": "Mbp/s", "cores": cores, "kind": "port",
+    out = {
+        "value": n * repeats * READ_LEN / dt / 1e6, "unit": "Mbp/s", "cores": cores, "kind": "port-tuned" if tuned else "port",
         "sample": f"first {n} reads of batch 0 x{repeats} passes ({n * repeats * READ_LEN / 1e9:.2f} Gbp, "
-                  f"{dt:.1f} s), oracle/ C restatement with a pthread pool over {cores} threads, same "
-                  f"{len(oidx):,}-key index",
+                  f"{dt:.1f} s), oracle/ C restatement{' (tuned form, same arithmetic)' if tuned else ''} with a pthread pool over "
+                  f"{cores} threads, same {len(oidx):,}-key index",
         "decisions_match_gpu": ok,
     }
+    if tuned:
+        # checked equal to the plain port on the reads both ran (keep, distinct hits, totals)
+        m = min(n, len(port_result[0])) if port_result is not None else 0
+        out["equals_port"] = bool(m > 0 and (keep[:m] == port_result[0][:m]).all() and (hits[:m] == port_result[1][:m]).all()
+                                  and (total[:m] == port_result[2][:m]).all())
+        out["per_core_Mbp_per_s"] = out["value"] / cores
+        out["reference_claim"] = "the reference's README quotes > 2 Gbp/s on an Apple M1 (README.md:14): other hardware, SIMD crates"
+    else:
+        out["_result"] = (keep, hits, total)
+    return out
 
 
 # ---- the host boundary: dcn_filter_batch* from host memory, PCIe included ----------------------------------------------
@@ -749,20 +783,8 @@ def main():
             host_path_all = {"error": repr(ex)}
     if rank == 0:
         total_bp = counters["total_bp"]
-        traffic = None  # HBM bytes per scan launch from the committed PMC passes (same workload only)
-        for name in ("r02_traffic.json", "r01_traffic.json"):
-            try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", name)))
-                wlk = tr["workload"]
-                if (args.workload == wlk["workload"] and batches[0].n_reads == wlk["reads_per_batch"]
-                        and int(index.n_keys) == wlk["index_keys"] and args.host_genome == wlk.get("host_genome_bases")):
-                    traffic = tr["scan_kernel"]["hbm_bytes_per_launch"]
-                    head["roofline"]["traffic_source"] = "profiles/" + name
-                    break
-            except Exception:
-                pass
         rf = head["roofline"]
-        rf["traffic"] = traffic
+        traffic = committed_traffic(rf, args.workload, batches[0].n_bases, int(index.n_keys), args.host_genome)
         try:
             rf["probe_only_kernel_live_per_s"] = probe_only_rate(index, device)
             rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
@@ -790,10 +812,6 @@ def main():
                 f"({time.time() - t_c:.1f} s)")
         except Exception as ex:
             log(f"probe ceiling measurement failed: {ex!r}")
-        if traffic:
-            # measured HBM traffic (PMC) over the live launch time: what the probe kernel really pulls from HBM
-            rf["traffic_rate_GBps"] = traffic / (rf["avg_launch_ms"] * 1e-3) / 1e9
-            rf["traffic_frac_of_peak"] = rf["traffic_rate_GBps"] / HBM_PEAK_GBS
         names = {"short": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
                  "paired": "configs[3]: paired 2x150 bp --deplete vs panhuman-1-sized index, inputs resident in HBM as ASCII",
                  "long": "configs[2]: ONT-style lognormal reads (mean 10 kbp) vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
@@ -834,7 +852,12 @@ def main():
                 log(f"CPU oracle set of {len(oidx):,} keys built with {cores} threads in {time.time() - t0:.1f} s (checker + cpu_baseline)")
             if world == 1 and not args.no_cpu_baseline and args.workload == "short":
                 out["cpu_baseline"] = cpu_baseline(oidx, cores, batches[0], params)
+                port_result = out["cpu_baseline"].pop("_result")
                 log(f"cpu_baseline: {out['cpu_baseline']['value']:.0f} Mbp/s on {cores} cores, decisions match: {out['cpu_baseline']['decisions_match_gpu']}")
+                out["cpu_baseline_tuned"] = cpu_baseline(oidx, cores, batches[0], params, seconds_target=8.0, tuned=True, port_result=port_result)
+                del port_result
+                log(f"cpu_baseline_tuned: {out['cpu_baseline_tuned']['value']:.0f} Mbp/s on {cores} cores, equals the port: "
+                    f"{out['cpu_baseline_tuned']['equals_port']}, decisions match: {out['cpu_baseline_tuned']['decisions_match_gpu']}")
             elif world == 1 and oidx is not None:
                 ok, what = check_against_oracle(oidx, batches[0], params, 300_000_000, cores)
                 out["decisions_match_gpu"] = ok
@@ -857,6 +880,7 @@ def main():
                     ok, what = check_against_oracle(oidx, bs[0], p, 200_000_000, cores)
                     r["decisions_match_gpu"], r["oracle_sample"] = ok, what + f" vs the oracle's {len(oidx):,}-key set (keep, hits, totals)"
                     r["workload"] = names[e]
+                    committed_traffic(r["roofline"], e, bs[0].n_bases, int(index.n_keys), args.host_genome)
                     workloads[e] = r
                     del bs
                     log(f"workloads.{e}: {r['value'] / 1e3:.1f} Gbp/s counting, {r['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, "
@@ -956,6 +980,8 @@ def main():
                         shape = ("configs[4]'s stream: half of the bases in ONT-style long reads (lognormal, mean 10 kbp), half in 150 bp "
                                  "reads, interleaved in one batch, --deplete" if kind_ == "mixed" else "paired 2x150 bp --deplete")
                         r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB); {shape}"
+                        if kind_ == "mixed":
+                            committed_traffic(r["roofline"], "mixed", bs[0].n_bases, int(idx3.n_keys), args.host_genome)
                         r["table_build_s"] = tb
                         workloads[key_] = r
                         del bs

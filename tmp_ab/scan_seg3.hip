@@ -95,6 +95,9 @@ struct WaveShared {
                   // finish are not written to their runs, 512 = their bookkeeping runs but the store itself is left out,
                   // 1024 = such units are not enrolled for the distinct pass (no tile_hits store, no atomics at the wave's end)
 #endif
+#ifndef DCN_HOIST_RUN
+#define DCN_HOIST_RUN 0 // 1: the run's next slot is also read from LDS before the probe resolves (two more live VGPRs)
+#endif
 #ifndef DCN_MIN_WAVES
 #define DCN_MIN_WAVES 4
 #endif
@@ -439,6 +442,25 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 if (valid[u] && !(DCN_EXP & 1)) g[u] = dcn_load_group(a.table, grp[u]);
             }
             if (PIPE && E + DCN_WAVE < M) fetch(E + DCN_WAVE, nxt); // behind the probe, ahead of its use
+            // What the export of hits (further down) needs and the probe's outcome does not decide, computed while the
+            // probe is in flight: where the lanes of each unit slot begin in this round (items are in flat order, so the
+            // lanes of a slot are adjacent and slots only grow with the lane), and the slot of the unit's run that the
+            // round's first hit would take.  Doing this after the probe put a cross-lane shuffle and two dependent LDS
+            // reads on every round's critical path: 13-19 % of the long-read scan (profiles/r03_long_split.txt).
+            unsigned long long segb[U];
+            uint32_t lok_hraw[U]; // bit 31: the item's unit is resolved in this wave; below: hits of it in earlier rounds
+#if DCN_HOIST_RUN
+            uint64_t run_next[U];
+#endif
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t up_us = __shfl_up(o_uslot[u], 1, 64);
+                segb[u] = __ballot(lane == 0 || up_us != o_uslot[u]);
+                lok_hraw[u] = DUMP ? 0u : (sh.hraw[o_uslot[u]] | ((uint32_t)sh.lok[o_uslot[u]] << 31));
+#if DCN_HOIST_RUN
+                run_next[u] = sh.run_base[o_uslot[u]] + sh.uhits[o_uslot[u]];
+#endif
+            }
             bool hit[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -462,11 +484,12 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const bool lok = hit[u] && sh.lok[o_uslot[u]];
+                if (U > 1 && u > 0) lok_hraw[u] = sh.hraw[o_uslot[u]] | ((uint32_t)sh.lok[o_uslot[u]] << 31); // moved by item u-1
+                const bool lok = hit[u] && (lok_hraw[u] >> 31);
                 // hits of units resolved in-wave: through the ring, compared with the unit's earlier hits.  Items
                 // are in flat order, so a unit's hits occupy consecutive ring slots: a hit with `run` earlier hits
-                // of its unit (earlier rounds: sh.hraw, this round: ballot arithmetic) compares with the `run`
-                // slots before it.
+                // of its unit (earlier rounds: sh.hraw, this round: ballot arithmetic over the lanes of its unit slot,
+                // whose first lane segb gives) compares with the `run` slots before it.
                 const unsigned long long hb = __ballot(lok);
                 if (hb) { // wave-uniform
                     const unsigned long long lt = (1ull << lane) - 1;
@@ -474,15 +497,9 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     const uint32_t rank = (uint32_t)__popcll(hb & lt);
                     const uint32_t x = n_ring + rank;
                     if (lok) sh.ring_hash[x & (DCN_RCAP - 1)] = hash[u];
-                    const unsigned long long below = hb & lt;
-                    const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
-                    const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
-                    const bool run_head = lok && (below == 0 || prev_us != o_uslot[u]);
-                    const unsigned long long hm_all = __ballot(run_head);
-                    const unsigned long long hm = hm_all & (lt | (1ull << lane));
-                    const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
-                    const uint32_t rank_head = (uint32_t)__popcll(hb & ((1ull << head_lane) - 1));
-                    const uint32_t run = lok ? sh.hraw[o_uslot[u]] + (rank - rank_head) : 0u;
+                    const uint32_t seg_first = 63u - (uint32_t)__clzll(segb[u] & (lt | (1ull << lane)));
+                    const unsigned long long from = ~((1ull << seg_first) - 1);
+                    const uint32_t run = lok ? (lok_hraw[u] & 0x7FFFFFFFu) + (uint32_t)__popcll(hb & lt & from) : 0u;
                     __syncthreads();
                     bool dup = false;
                     for (uint32_t d0 = 0; __any(d0 < ((DCN_EXP & 8) ? 0u : run)); d0 += 4) {
@@ -496,12 +513,14 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     // a unit's hits of this round are one run of adjacent hit lanes: its first lane books the whole run
                     // (one LDS update per run instead of a same-address atomic per hit lane)
                     const unsigned long long db = __ballot(dup);
-                    if (run_head) {
-                        const unsigned long long later = hm_all & ~((2ull << lane) - 1);
+                    if ((uint32_t)lane == seg_first) { // one update per unit slot and round
+                        const unsigned long long later = segb[u] & ~((2ull << lane) - 1);
                         const unsigned long long upto = later ? ((1ull << (__ffsll((long long)later) - 1)) - 1) : ~0ull;
-                        const unsigned long long rm = hb & upto & ~lt;
-                        sh.hraw[o_uslot[u]] += (uint32_t)__popcll(rm);
-                        sh.hits[o_uslot[u]] += (uint32_t)__popcll(rm & ~db);
+                        const unsigned long long rm = hb & from & upto;
+                        if (rm) {
+                            atomicAdd(&sh.hraw[o_uslot[u]], (uint32_t)__popcll(rm));
+                            atomicAdd(&sh.hits[o_uslot[u]], (uint32_t)__popcll(rm & ~db));
+                        }
                     }
                     n_ring += nh;
                     __syncthreads();
@@ -518,24 +537,25 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     const unsigned long long rb = (DCN_EXP & 256) ? 0ull : __ballot(rec);
                     if (rb) { // wave-uniform
                         const unsigned long long lt = (1ull << lane) - 1;
-                        const unsigned long long below = rb & lt;
-                        const uint32_t prev_lane = below ? 63u - (uint32_t)__clzll(below) : (uint32_t)lane;
-                        const uint32_t prev_us = __shfl(o_uslot[u], prev_lane, 64);
-                        const bool run_head = rec && (below == 0 || prev_us != o_uslot[u]);
-                        const unsigned long long hm_all = __ballot(run_head);
-                        const unsigned long long hm = hm_all & (lt | (1ull << lane));
-                        const uint32_t head_lane = hm ? 63u - (uint32_t)__clzll(hm) : 0u;
-                        const uint32_t rank = (uint32_t)__popcll(below) - (uint32_t)__popcll(rb & ((1ull << head_lane) - 1));
+                        // first lane of this lane's unit slot in this round (bit 0 of segb is always set)
+                        const uint32_t seg_first = 63u - (uint32_t)__clzll(segb[u] & (lt | (1ull << lane)));
+                        const unsigned long long from = ~((1ull << seg_first) - 1);
                         any_rec = true;
                         if (rec) {
-                            const uint32_t before = sh.uhits[o_uslot[u]];
-                            if (!(DCN_EXP & 512)) a.rec_hash[sh.run_base[o_uslot[u]] + before + rank] = hash[u];
+                            // (more than one item per lane and round: the earlier items of this round moved the run's end)
+#if DCN_HOIST_RUN
+                            const uint64_t slot = (U > 1 && u > 0) ? sh.run_base[o_uslot[u]] + sh.uhits[o_uslot[u]] : run_next[u];
+#else
+                            const uint64_t slot = sh.run_base[o_uslot[u]] + sh.uhits[o_uslot[u]];
+#endif
+                            if (!(DCN_EXP & 512)) a.rec_hash[slot + (uint32_t)__popcll(rb & lt & from)] = hash[u];
                             if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
-                        if (run_head) { // after every lane of the run has read the old length: one update per run
-                            const unsigned long long later = hm_all & ~((2ull << lane) - 1);
+                        if ((uint32_t)lane == seg_first) { // one update of the run's length per unit slot and round
+                            const unsigned long long later = segb[u] & ~((2ull << lane) - 1);
                             const unsigned long long upto = later ? ((1ull << (__ffsll((long long)later) - 1)) - 1) : ~0ull;
-                            sh.uhits[o_uslot[u]] += (uint32_t)__popcll(rb & upto & ~lt);
+                            const uint32_t n_new = (uint32_t)__popcll(rb & from & upto);
+                            if (n_new) atomicAdd(&sh.uhits[o_uslot[u]], n_new);
                         }
                     }
                 }

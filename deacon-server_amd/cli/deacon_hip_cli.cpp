@@ -53,13 +53,20 @@ namespace {
 
 const char *VERSION = "0.2.0";
 
-std::atomic<int> g_sparse_out_fd{-1};  // output file still sized to its reservation (MappedOutput): cut on failure
+std::atomic<int> g_sparse_out_fds[2] = {{-1}, {-1}};  // output files still sized to their reservation (MappedOutput): cut on failure
+
+void cut_sparse_outputs() {  // async-signal-safe
+    for (auto &g : g_sparse_out_fds) {
+        int fd = g.exchange(-1);
+        if (fd >= 0 && ftruncate(fd, 0) != 0) {
+        }
+    }
+}
 
 [[noreturn]] void die(const std::string &msg) {
     std::fprintf(stderr, "Error: %s\n", msg.c_str());
     std::fflush(nullptr);
-    int fd = g_sparse_out_fd.exchange(-1);
-    if (fd >= 0 && ftruncate(fd, 0) != 0) std::fprintf(stderr, "Error: could not truncate the output file\n");
+    cut_sparse_outputs();
     _exit(1);  // callable from any pipeline thread while the others are still running
 }
 
@@ -411,6 +418,7 @@ struct Batch {
     std::vector<std::vector<uint64_t>> sub_off;
     std::vector<std::vector<uint32_t>> sub_uid;
     uint64_t out_off = 0, out_bytes = 0;  // mapped output: where this batch's kept records go, and how many bytes
+    uint64_t out_off2 = 0, out_bytes2 = 0;  // ... and the second mates', when they have a mapped file of their own (-O)
     size_t raw_end = 0;     // chunk reader: `text` holds raw input, whole records in [0, raw_end) ...
     bool raw_fastq = false;  // ... of this format
     bool paired = false;
@@ -438,6 +446,7 @@ struct Batch {
         sub_off.clear();
         sub_uid.clear();
         out_off = out_bytes = 0;
+        out_off2 = out_bytes2 = 0;
         raw_end = 0;
         raw_fastq = false;
         paired = false;
@@ -1062,14 +1071,16 @@ inline unsigned decimal_digits(uint64_t v) {
     return n;
 }
 
-// bytes format_batch would produce for the kept records of a batch (single-file output)
-uint64_t formatted_size(const Batch &b, bool rename, uint64_t rename_base) {
+// bytes format_batch would produce for the kept records of a batch; mate >= 0: only for that mate of every pair
+// (two output files, -o / -O), numbered as in the single stream
+uint64_t formatted_size(const Batch &b, bool rename, uint64_t rename_base, int mate = -1) {
     uint64_t n = 0, counter = rename_base;
     const size_t per_unit = b.paired ? 2 : 1;
     for (size_t i = 0; i < b.recs.size(); ++i) {
         if (!b.keep[i / per_unit]) continue;
         const Rec &r = b.recs[i];
         ++counter;
+        if (mate >= 0 && (int)(i & 1) != mate) continue;
         if (r.rec_len && !rename) n += r.rec_len;
         else n += 1 + (rename ? decimal_digits(counter) : r.id_len) + 1 + r.seq_len + (r.qual_off == NO_QUAL ? 1 : 4 + (uint64_t)r.seq_len);
     }
@@ -1078,7 +1089,7 @@ uint64_t formatted_size(const Batch &b, bool rename, uint64_t rename_base) {
 
 // the same records written straight to `dst` (the output file's mapping at this batch's offset): one memcpy per
 // run of adjacent kept records whose input bytes can be taken as they are, field by field otherwise
-BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base, char *dst, uint64_t expect) {
+BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base, char *dst, uint64_t expect, int mate = -1) {
     BatchStats st;
     const char *chars = b.chars();
     const size_t per_unit = b.paired ? 2 : 1;
@@ -1102,6 +1113,7 @@ BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base
         st.output_bp += r.seq_len;
         st.kept_records++;
         counter++;
+        if (mate >= 0 && (int)(i & 1) != mate) continue;  // the other file's mate (the statistics count both: take one call's)
         if (r.rec_len && !rename) {
             if (run_len && run_off + run_len == r.rec_off) run_len += r.rec_len;
             else flush_run(), run_off = r.rec_off, run_len = r.rec_len;
@@ -1230,7 +1242,8 @@ class MappedOutput {
         }
         data_ = (char *)p;
         reserve_ = reserve;
-        g_sparse_out_fd = fd_;
+        slot_ = g_sparse_out_fds[0].load() < 0 ? 0 : 1;
+        g_sparse_out_fds[slot_] = fd_;
 #ifdef MADV_HUGEPAGE
         (void)madvise(p, reserve, MADV_HUGEPAGE);  // where the filesystem honours it: 512x fewer first-touch faults
 #endif
@@ -1242,9 +1255,7 @@ class MappedOutput {
             static const char msg[] = "Error: write error (output file could not grow)\n";
             ssize_t ignored = ::write(2, msg, sizeof msg - 1);
             (void)ignored;
-            int fd = g_sparse_out_fd.exchange(-1);
-            if (fd >= 0 && ftruncate(fd, 0) != 0) {
-            }
+            cut_sparse_outputs();
             _exit(1);
         };
         sigaction(SIGBUS, &sa, nullptr);
@@ -1252,9 +1263,7 @@ class MappedOutput {
         struct sigaction si;
         std::memset(&si, 0, sizeof si);
         si.sa_handler = [](int sig) {
-            int fd = g_sparse_out_fd.exchange(-1);
-            if (fd >= 0 && ftruncate(fd, 0) != 0) {
-            }
+            cut_sparse_outputs();
             _exit(128 + sig);
         };
         for (int sig : {SIGINT, SIGTERM, SIGHUP}) sigaction(sig, &si, nullptr);
@@ -1268,7 +1277,7 @@ class MappedOutput {
         if (fd_ < 0) return;
         // a filesystem that defers allocation errors to writeback only shows them to msync / fsync
         if (sync_at_end_ && bytes && msync(data_, bytes, MS_SYNC) != 0) die("write error");
-        g_sparse_out_fd = -1;
+        g_sparse_out_fds[slot_] = -1;
         if (munmap(data_, reserve_) != 0 || ftruncate(fd_, (off_t)bytes) != 0) die("write error");
         if (sync_at_end_ && fdatasync(fd_) != 0) die("write error");
         if (::close(fd_) != 0) die("write error");
@@ -1280,6 +1289,7 @@ class MappedOutput {
     int fd_ = -1;
     char *data_ = nullptr;
     uint64_t reserve_ = 0;
+    int slot_ = 0;
     bool sync_at_end_ = false;
 };
 
@@ -1412,16 +1422,28 @@ int run_filter(const FilterArgs &a) {
     const bool plain_out = a.output != "-" && !ends_with(a.output, ".gz") && !ends_with(a.output, ".zst") && !ends_with(a.output, ".xz");
     // (one write(2) / writev(2) stream moves 4.8-6.6 GB/s on tmpfs and stalls the stages in front of it: 0.90-0.95 s
     // against 0.68-0.76 s through the mapping for the same 5 GB input, profiles/r02_cli_bench.txt)
-    if ((parallel_in || (pair_in && !a.has_output2)) && plain_out && !std::getenv("DCN_CLI_NO_MMAP_OUT"))
-        mapped_out.open(a.output, 5 * ((uint64_t)mapped.size + (pair_in ? mapped2.size : 0)) + (1u << 20));  // >= any formatted size (renamed ids: <= 20 digits)
+    // two plain files of mates written to two plain files (-o / -O, the usual shape of a paired run): each output is mapped
+    // and takes its own mate of every kept pair
+    MappedOutput mapped_out2;
+    const bool plain_out2 = a.has_output2 && a.output2 != "-" && !ends_with(a.output2, ".gz") && !ends_with(a.output2, ".zst") && !ends_with(a.output2, ".xz");
+    const bool split_mapped = pair_in && a.has_output2 && plain_out && plain_out2 && a.output2 != a.output;
+    if ((parallel_in || (pair_in && (!a.has_output2 || split_mapped))) && plain_out && !std::getenv("DCN_CLI_NO_MMAP_OUT")) {
+        const uint64_t in1 = (uint64_t)mapped.size, in2 = pair_in ? (uint64_t)mapped2.size : 0;
+        // >= any formatted size (renamed ids: <= 20 digits)
+        if (mapped_out.open(a.output, 5 * (split_mapped ? in1 : in1 + in2) + (1u << 20)) && split_mapped &&
+            !mapped_out2.open(a.output2, 5 * in2 + (1u << 20)))
+            die("Failed to map the second output file: " + a.output2 + " (DCN_CLI_NO_MMAP_OUT=1 writes through write(2))");
+    }
     const bool map_out = mapped_out.active();
+    const bool map_out2 = map_out && mapped_out2.active();
     std::unique_ptr<Output> out1_holder;
     if (!map_out) out1_holder.reset(new Output(a.output, a.compression_level));
     // plain single-file output: the formatter only lists what to write, the writer thread gathers it with writev
     const bool gather_out = !map_out && out1_holder->plain() && !(a.has_output2 && paired) && !std::getenv("DCN_CLI_NO_GATHER");
     std::unique_ptr<Output> out2;
-    if (a.has_output2 && paired) out2.reset(new Output(a.output2, a.compression_level));
-    else if (a.has_output2 && !quiet) std::fprintf(stderr, "Warning: --output2 specified but no second input file provided. --output2 will be ignored.\n");
+    if (a.has_output2 && paired) {
+        if (!map_out2) out2.reset(new Output(a.output2, a.compression_level));
+    } else if (a.has_output2 && !quiet) std::fprintf(stderr, "Warning: --output2 specified but no second input file provided. --output2 will be ignored.\n");
 
     const uint64_t batch_bases = 1ull << 26;
     const uint32_t batch_reads = 1u << 20;
@@ -1633,7 +1655,8 @@ int run_filter(const FilterArgs &a) {
     BatchStats tot;
     OrderedStage format_stage(pool_in ? n_workers : 2, 2 * n_workers + 2, [&](Batch &b) {
         StageClock::Scope sc(t_format);
-        BatchStats st = map_out ? format_batch_mapped(b, a.rename, b.seq_no, mapped_out.at(b.out_off, b.out_bytes), b.out_bytes)
+        if (map_out2) format_batch_mapped(b, a.rename, b.seq_no, mapped_out2.at(b.out_off2, b.out_bytes2), b.out_bytes2, 1);
+        BatchStats st = map_out ? format_batch_mapped(b, a.rename, b.seq_no, mapped_out.at(b.out_off, b.out_bytes), b.out_bytes, map_out2 ? 0 : -1)
                         : gather_out ? format_batch_gather(b, a.rename, b.seq_no)
                                      : format_batch(b, a.rename, split_mates, b.seq_no /* rename base, set by the GPU stage */);
         if (!map_out && !gather_out && !out1_holder->plain()) {  // this batch's member(s), compressed on this worker
@@ -1728,7 +1751,7 @@ int run_filter(const FilterArgs &a) {
             r0 = r1;
         }
     };
-    uint64_t out_bytes_total = 0;  // mapped output: bytes placed so far
+    uint64_t out_bytes_total = 0, out_bytes_total2 = 0;  // mapped outputs: bytes placed so far
     std::unique_ptr<deacon::FilterProcessor> debug_proc;  // only --debug re-scans batches (for the k-mer strings)
     std::thread feeder([&] {
         std::unique_ptr<Batch> b;
@@ -1767,8 +1790,13 @@ int run_filter(const FilterArgs &a) {
             for (size_t u = 0; u < n_units; ++u) kept_units += b->keep[u] != 0;
             if (map_out) {  // this batch's place in the output file
                 b->out_off = out_bytes_total;
-                b->out_bytes = formatted_size(*b, a.rename, written_before);
+                b->out_bytes = formatted_size(*b, a.rename, written_before, map_out2 ? 0 : -1);
                 out_bytes_total += b->out_bytes;
+                if (map_out2) {
+                    b->out_off2 = out_bytes_total2;
+                    b->out_bytes2 = formatted_size(*b, a.rename, written_before, 1);
+                    out_bytes_total2 += b->out_bytes2;
+                }
             }
             written_before += kept_units * (b->paired ? 2 : 1);
             StageClock::Scope sc(t_push_wait);
@@ -1783,6 +1811,7 @@ int run_filter(const FilterArgs &a) {
     m_written = std::chrono::duration<double>(clock::now() - start).count();
     if (map_out) mapped_out.finish(out_bytes_total);
     else out1_holder->close();
+    if (map_out2) mapped_out2.finish(out_bytes_total2);
     if (out2) out2->close();
     uint64_t total_seqs = tot.total_seqs, filtered_seqs = tot.filtered_seqs, total_bp = tot.total_bp,
              output_bp = tot.output_bp, filtered_bp = tot.filtered_bp;

@@ -5,7 +5,7 @@
 # usage: bash profiles/collect_r3.sh     -> gpurun_out/r3_{stats,pmc}_*; profiles/make_traffic_json.py turns them into profiles/r03_*
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-keys() { [ "$1" = mixed ] && echo "--index-keys 950000000"; }  # the mixed stream is configs[4]'s: against the 950 M-key union table
+keys() { if [ "$1" = mixed ]; then echo "--index-keys 950000000"; fi; }  # the mixed stream is configs[4]'s: against the 950 M-key union table
 for wl in short long mixed; do
   ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-extras --workload $wl $(keys $wl)"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3_stats_$wl -o trace -- python3 bench.py $ARGS \

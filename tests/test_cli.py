@@ -579,6 +579,12 @@ def test_paired_files_in_parallel_match_the_record_reader(tmp_path, monkeypatch)
             monkeypatch.delenv("DCN_CLI_NO_PAIR_MMAP", raising=False)
         assert outs["pool"] == outs["reader"], extra
         assert outs["pool"][0] == outs["pool"][1] and (extra == ["-d"] or len(outs["pool"][0]) > 100_000)
+        # -o / -O to two plain files goes through two output mappings (round 3); the write(2) path must agree
+        monkeypatch.setenv("DCN_CLI_NO_MMAP_OUT", "1")
+        run("filter", idx, r1, r2, "-t", 5, "-o", tmp_path / "w1.fq", "-O", tmp_path / "w2.fq", *extra)
+        monkeypatch.delenv("DCN_CLI_NO_MMAP_OUT")
+        assert [(tmp_path / "w1.fq").read_bytes(), (tmp_path / "w2.fq").read_bytes()] == outs["pool"][2:4], extra
+        assert outs["pool"][2].count(b"\n") == outs["pool"][3].count(b"\n") > 0 or extra == ["-d"]  # mate for mate
     # a file of mates that ends early, or runs on, is an error either way
     r2.write_bytes(b"".join(l2[:-3]))
     p = run("filter", idx, r1, r2, check=False)

@@ -251,6 +251,13 @@ def file_to_file(index, genome_dev, host_keys_sorted, n_rand, make_reads, make_p
                              "format": "bincode-2 varint, src/index.rs:130-164"}
         log(f"cli: index file of {out['index_file']['bytes'] / 1e9:.2f} GB written in {out['index_file']['write_s']:.1f} s")
         device = genome_dev.device
+        # the first process to load the file is not one of the timed legs: the time a fresh process takes to get the 34 GB
+        # table up was seen to vary from 0.28 to 1.26 s on the same files (box state, not the tool); it is reported beside them
+        warm_fq = os.path.join(d, "warm.fq")
+        fastq_records(np.full((1000, READ_LEN), ord("A"), np.uint8)).tofile(warm_fq)
+        w = filter_run(idx_path, [warm_fq], [os.path.join(d, "warm.out.fq")], [], os.path.join(d, "s.json"))
+        out["index_file"]["first_load_s"] = w["index_load_s"]
+        out["index_file"]["first_run_wall_s"] = w["run_wall_s"]
 
         def check(inputs_seqs, uid, deplete, out_path, n_units):
             """kept ids among the first reads of the input vs the oracle on the index keys that sample can touch"""

@@ -387,6 +387,8 @@ struct dcn_ctx {
     // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
     // units whose hits do not fit the LDS set of the distinct pass (4 slots per record of capacity)
     uint64_t *d_rec_hash = nullptr;
+    char *d_slab = nullptr;      // DCN_CTX_SLAB: one allocation behind the fixed-size buffers above
+    uint64_t slab_bytes = 0;
     uint32_t *d_tile_hits = nullptr, *d_pending = nullptr;
     uint2 *d_big = nullptr; // work items of the distinct pass B: at most one per 64 tiles + one per unit
     uint64_t rec_capacity = 0;
@@ -477,7 +479,8 @@ void free_ctx(dcn_ctx *c) {
                    c->d_set_off, c->d_tile_hits, c->d_pending, c->d_big, c->d_rec_hash, c->d_set_slots, c->d_status, c->d_report, c->d_dump_hash,
                    c->d_dump_pos, c->d_dump_count, c->d_dump_valid, c->d_tile_read_pos};
     for (void *p : dev)
-        if (p) hipFree(p);
+        if (p && !((char *)p >= c->d_slab && (char *)p < c->d_slab + c->slab_bytes)) hipFree(p);
+    if (c->d_slab) hipFree(c->d_slab);
     for (int i = 0; i < dcn_ctx::N_STAGE; ++i) {
         if (c->h_stage[i]) hipHostFree(c->h_stage[i]);
         if (c->stage_free[i]) hipEventDestroy(c->stage_free[i]);
@@ -1027,8 +1030,26 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
              hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) return fail(dcn_fail(DCN_ERR_HIP, "stream/event creation failed"));
     uint64_t MR = max_batch_reads;
-#define A(ptr, count, what)                          \
-    if ((rc = dev_alloc(&c->ptr, (count), what)) != DCN_OK) return fail(rc)
+    // DCN_CTX_SLAB=1 (experiment, profiles/placement_order.py): the fixed-size buffers below come out of ONE allocation,
+    // each on a 2 MB boundary, instead of 24 separate ones
+    const bool slab = getenv("DCN_CTX_SLAB") != nullptr;
+    uint64_t slab_off = 0;
+    for (int pass = slab ? 0 : 1; pass < 2; ++pass) {
+        if (slab && pass == 1) {
+            c->slab_bytes = slab_off;
+            if (hipMalloc((void **)&c->d_slab, c->slab_bytes) != hipSuccess) {
+                c->d_slab = nullptr;
+                c->slab_bytes = 0;
+                return fail(dcn_fail(DCN_ERR_NOMEM, "hipMalloc of the context slab failed"));
+            }
+            slab_off = 0;
+        }
+#define A(ptr, count, what)                                                                                   \
+    if (slab) {                                                                                               \
+        if (pass == 1) c->ptr = reinterpret_cast<decltype(c->ptr)>(c->d_slab + slab_off);                     \
+        slab_off += (std::max<uint64_t>((count), 1) * sizeof(*c->ptr) + (2u << 20) - 1) / (2u << 20) * (2u << 20); \
+    } else if ((rc = dev_alloc(&c->ptr, (count), what)) != DCN_OK)                                            \
+        return fail(rc)
     A(d_ascii, max_batch_bases + 64, "ascii");
     A(d_offsets, MR + 1, "offsets");
     A(d_unit_id, MR, "unit_id");
@@ -1054,6 +1075,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_status, 1, "status");
     A(d_report, 1, "report");
 #undef A
+    }
     // global sets of the distinct pass (only units with more hits than its LDS set holds use them): sized for the
     // expected long-read density, grown on demand by the host API / dcn_ctx_reserve_records
     uint64_t recs = std::min<uint64_t>(std::max<uint64_t>(max_batch_bases / 16, 1u << 16), 1ull << 29);

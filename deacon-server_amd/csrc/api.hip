@@ -156,6 +156,8 @@ static int same_params(const dcn_index *a, const dcn_index *b) {
         return dcn_fail(DCN_ERR_ARG, "Incompatible headers: k=" + std::to_string((int)b->k) + ", w=" + std::to_string((int)b->w) +
                                          " vs k=" + std::to_string((int)a->k) + ", w=" + std::to_string((int)a->w));
     if (a->device != b->device) return dcn_fail(DCN_ERR_ARG, "indexes live on different devices");
+    if (a->variant != b->variant)
+        return dcn_fail(DCN_ERR_ARG, "indexes were created under different minimizer rules (dcn_set_minimizer_variant)");
     return DCN_OK;
 }
 
@@ -173,6 +175,7 @@ extern "C" int dcn_index_union(const dcn_index *const *inputs, uint32_t n, dcn_i
     dcn_index *idx = new (std::nothrow) dcn_index();
     if (!idx) return dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
     idx->device = inputs[0]->device;
+    idx->variant = inputs[0]->variant;
     idx->k = inputs[0]->k;
     idx->w = inputs[0]->w;
     int rc = dcn_table_alloc(idx, std::max<uint64_t>(sum, 16));
@@ -195,6 +198,7 @@ extern "C" int dcn_index_diff(const dcn_index *first, const dcn_index *second, d
     dcn_index *idx = new (std::nothrow) dcn_index();
     if (!idx) return dcn_fail(DCN_ERR_NOMEM, "host allocation failed");
     idx->device = first->device;
+    idx->variant = first->variant;
     idx->k = first->k;
     idx->w = first->w;
     rc = dcn_table_alloc(idx, std::max<uint64_t>(first->n_keys, 16));
@@ -619,6 +623,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     sa.unit_tile_count = c->d_unit_tile_count;
     sa.table = idx->view();
     sa.k = idx->k;
+    sa.variant = idx->variant;
     sa.w = idx->w;
     sa.stream_bases = v.stream_bases;
     sa.abs_threshold = params->abs_threshold;
@@ -1778,6 +1783,7 @@ extern "C" int dcn_minimizer_hashes_batch(dcn_ctx *ctx, const uint8_t *bases, co
     sa.n_tiles = &c->d_status->n_tiles;
     sa.table = c->index->view();
     sa.k = c->index->k;
+    sa.variant = c->index->variant;
     sa.w = c->index->w;
     sa.stream_bases = n_bases;
     sa.status = c->d_status;
@@ -2005,6 +2011,7 @@ int dcn_build_index_impl(const uint8_t *bases, const uint64_t *offsets, uint32_t
             sa.n_tiles = &c->d_status->n_tiles;
             sa.table = idx->view();
             sa.k = idx->k;
+            sa.variant = idx->variant;
             sa.w = idx->w;
             sa.stream_bases = nb;
             sa.status = c->d_status;

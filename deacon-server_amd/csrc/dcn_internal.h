@@ -48,7 +48,14 @@ struct dcn_table_view {
     uint32_t has_zero;
 };
 
+// the minimizer rule in force (dcn_set_minimizer_variant): rotation << 16 | compared bits << 8 | combine
+constexpr uint32_t DCN_VARIANT_DEFAULT = (1u << 16) | (16u << 8) | 0u;
+uint32_t dcn_current_variant();
+
 struct dcn_index {
+    // captured when the index is created (built, loaded, merged, cloned): the rule its keys were selected by travels
+    // with it, and every context filters by its index's rule whatever the process-wide setting has become since
+    uint32_t variant = dcn_current_variant();
     int device = 0;
     uint8_t k = 0, w = 0;
     uint64_t n_keys = 0; // distinct
@@ -164,6 +171,7 @@ struct dcn_scan_args {
     uint32_t *dump_count; // per tile
     uint32_t dump_abs;    // 1: dump_pos holds the low 32 bits of the absolute base index instead of the read position
     // parity-pinning variant (scan_kernel<..., VAR>; filled in by dcn_launch_scan from dcn_set_minimizer_variant)
+    uint32_t variant;        // the index's dcn_index::variant (0: the default rules)
     uint32_t nt_rot;         // ntHash rotation per base (1)
     uint32_t cmp_mask;       // hash bits that are compared (0xFFFF0000)
     uint32_t nt_combine_xor; // 0: fw + rc, 1: fw ^ rc

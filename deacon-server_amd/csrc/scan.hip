@@ -957,8 +957,10 @@ int launch_w(const dcn_scan_args &args, uint32_t blocks, bool dump, bool k128, s
 
 // ---- the parity-pinning variant (process-wide) ---------------------------------------------------
 namespace {
-std::atomic<uint32_t> g_variant{(1u << 16) | (16u << 8) | 0u}; // rot << 16 | cmp_bits << 8 | combine
+std::atomic<uint32_t> g_variant{DCN_VARIANT_DEFAULT}; // rot << 16 | cmp_bits << 8 | combine
 }
+
+uint32_t dcn_current_variant() { return g_variant.load(); }
 
 int dcn_set_minimizer_variant(uint32_t nt_rot, uint32_t cmp_bits, uint32_t combine) {
     if (nt_rot < 1 || nt_rot > 31) return dcn_fail(DCN_ERR_ARG, "minimizer variant: rotation must be 1..31");
@@ -980,8 +982,8 @@ int dcn_launch_scan(const dcn_scan_args &args_in, uint32_t max_tiles, bool dump,
     if (max_tiles == 0) return DCN_OK;
     uint32_t blocks = (max_tiles + DCN_WAVE - 1) / DCN_WAVE;
     bool k128 = args_in.k > 32;
-    const uint32_t v = g_variant.load();
-    if (v != ((1u << 16) | (16u << 8) | 0u)) {
+    const uint32_t v = args_in.variant ? args_in.variant : DCN_VARIANT_DEFAULT; // the index's rule, not the process's
+    if (v != DCN_VARIANT_DEFAULT) {
         // not the rules of SURVEY.md 8a row A4: one generic kernel with the three choices as run-time values
         dcn_scan_args args = args_in;
         args.nt_rot = v >> 16;

@@ -73,8 +73,10 @@ int dcn_device_count(int *count);
  * of its details could not be executed where this library was written ("Notes on A4"): the ntHash
  * rotation per base (1, or 7 as in the crate's later line), how many hash bits the window minimum compares (the top
  * 16, or all 32) and how the two strands' hashes are combined (wrapping add, or xor).  The defaults are (1, 16, 0).
- * Process-wide; set it before the first index is built or loaded -- an index and the reads filtered against it must
- * use the same rule.  Any other setting runs a generic kernel (slower, counting mode only); tests/golden/
+ * The setting is process-wide and is CAPTURED by every index when it is created (built, loaded, merged, cloned): the
+ * rule an index's keys were selected by travels with it, every context filters by its index's rule whatever the
+ * setting has become since, and union / diff refuse operands created under different rules.  Set it before the first
+ * index is built or loaded.  Any other setting than the default runs a generic kernel (slower, counting mode only); tests/golden/
  * dump_crate_vectors prints vectors from the real crates, and tests/test_crate_vectors.py names the setting that
  * reproduces them. */
 int dcn_set_minimizer_variant(uint32_t nt_rot, uint32_t cmp_bits, uint32_t combine /* 0: fw + rc, 1: fw ^ rc */);

@@ -35,6 +35,17 @@ int main(void) {
     int ndev = -1;
     rc = dcn_device_count(&ndev); /* DCN_OK with a GPU, DCN_ERR_HIP without: either way no abort and a defined count */
     if (ndev < 0) return 8;
+    /* the parity-pinning switch: argument errors are refused, a valid setting reads back, the default is (1, 16, 0) */
+    uint32_t rot = 0, bits = 0, comb = 9;
+    if (dcn_get_minimizer_variant(&rot, &bits, &comb) != DCN_OK || rot != 1 || bits != 16 || comb != 0) return 10;
+    if (dcn_set_minimizer_variant(0, 16, 0) != DCN_ERR_ARG || dcn_set_minimizer_variant(1, 24, 0) != DCN_ERR_ARG ||
+        dcn_set_minimizer_variant(1, 16, 2) != DCN_ERR_ARG)
+        return 11;
+    if (dcn_set_minimizer_variant(7, 32, 1) != DCN_OK || dcn_get_minimizer_variant(&rot, &bits, &comb) != DCN_OK ||
+        rot != 7 || bits != 32 || comb != 1 || dcn_set_minimizer_variant(1, 16, 0) != DCN_OK)
+        return 12;
+    double rate = -1.0;
+    if (dcn_index_probe_ceiling(NULL, NULL, 10, 1, &rate) != DCN_ERR_ARG) return 13;
     printf("%s devices=%d rc=%d\n", v, ndev, rc);
     return 0;
 }

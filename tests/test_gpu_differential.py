@@ -81,6 +81,43 @@ def test_differential_under_every_minimizer_variant(oracle, dcn, variant, monkey
         dcn.set_minimizer_variant(*DEFAULT_VARIANT)
 
 
+def test_the_minimizer_variant_travels_with_the_index(oracle, dcn):
+    """dcn_set_minimizer_variant is process-wide, but an index captures the setting it was created under: a context
+    filters by its index's rule whatever the setting has become since, and set algebra refuses mixed operands."""
+    rng = np.random.default_rng(5)
+    genome = random_reads(rng, 1, 30_000, 30_000)[0]
+    reads = [genome[s:s + 200] for s in range(0, 20_000, 170)] + random_reads(rng, 50, 150, 150)
+    b, o = oracle.concat_reads(reads)
+    other = (7, 32, "xor")
+    try:
+        oi_def = oracle.Index.build([genome])
+        gi_def = dcn.Index.build([genome], 31, 15)                     # created under the default rules
+        want_def = oracle.filter_batch(oi_def, b, o)
+        oracle.set_variant(*other)
+        dcn.set_minimizer_variant(*other)
+        oi_var = oracle.Index.build([genome])
+        gi_var = dcn.Index.build([genome], 31, 15)                     # created under (7, 32, xor)
+        want_var = oracle.filter_batch(oi_var, b, o)
+        assert sorted(gi_var.keys().tolist()) == sorted(oi_var.keys().tolist()) != sorted(oi_def.keys().tolist())
+        for gi, want in ((gi_def, want_def), (gi_var, want_var)):      # the process-wide setting is still (7, 32, xor)
+            proc = dcn.FilterProcessor(gi, max_batch_bases=len(b) + 64, max_batch_reads=len(reads) + 1)
+            got = proc.filter_batch(b, o)
+            assert all(g.tolist() == w.tolist() for g, w in zip(got, want))
+            proc.close()
+        dcn.set_minimizer_variant(*DEFAULT_VARIANT)                     # ... and after switching back as well
+        proc = dcn.FilterProcessor(gi_var, max_batch_bases=len(b) + 64, max_batch_reads=len(reads) + 1)
+        assert all(g.tolist() == w.tolist() for g, w in zip(proc.filter_batch(b, o), want_var))
+        proc.close()
+        with pytest.raises(dcn.DeaconHipError, match="different minimizer rules"):
+            dcn.Index.union([gi_def, gi_var])
+        with pytest.raises(dcn.DeaconHipError, match="different minimizer rules"):
+            gi_def.diff(gi_var)
+        assert sorted(gi_var.clone(0).keys().tolist()) == sorted(oi_var.keys().tolist())
+    finally:
+        oracle.set_variant(*DEFAULT_VARIANT)
+        dcn.set_minimizer_variant(*DEFAULT_VARIANT)
+
+
 def run_seed(oracle, dcn, seed, monkeypatch, n_cases):
     rng = np.random.default_rng(1000 + seed)
     genome = random_reads(rng, 1, 60_000, 60_000)[0]

@@ -623,3 +623,69 @@ def test_config1_plumbing_at_its_stated_shape(tmp_path):
     assert r["search"]["seqs_out"] + r["deplete"]["seqs_out"] == 10_000
     assert 4_900 <= r["search"]["seqs_out"] <= 5_100
     assert r["decisions_match"]
+
+
+# ---- the host-side parser under AddressSanitizer / UBSan (CPU build only: GPU sanitizers are not available on the pool) ------
+def test_parser_pool_under_sanitizers(tmp_path):
+    """`deacon-hip bench-parse` (the parser pool of the mapped-input path, no GPU) built with -fsanitize=address,undefined
+    and run over hostile FASTA / FASTQ: CRLF, '+id' lines, qualities starting with '@', blank lines, empty sequences, a
+    missing final newline, truncated records, multi-line and one-base-per-line FASTA, binary garbage.  Malformed input
+    must end in the tool's own error; a sanitizer report fails the test."""
+    exe = tmp_path / "deacon-hip-asan"
+    pkg = os.path.join(ROOT, "deacon-server_amd")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined",
+           "-I", os.path.join(ROOT, "include"), os.path.join(pkg, "cli", "deacon_hip_cli.cpp"), "-o", str(exe),
+           "-L", os.path.join(pkg, "lib"), "-ldeacon_hip", "-lz", "-ldl", "-lpthread", f"-Wl,-rpath,{os.path.join(pkg, 'lib')}",
+           "-Wl,--allow-shlib-undefined"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0 and ("asan" in p.stderr.lower() or "ubsan" in p.stderr.lower() or "sanitize" in p.stderr.lower()):
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACGTNacgtn", dtype=np.uint8)
+
+    def seq(n):
+        return alpha[rng.integers(0, len(alpha), n)].tobytes()
+
+    def fq(n, crlf=False, plus_id=False, at_qual=False, blank=False, no_final_nl=False, trunc=0, empty=False):
+        out = []
+        for i in range(n):
+            ln = int(rng.integers(0 if empty else 1, 400))
+            q = (b"@" + bytes(rng.integers(33, 74, ln - 1, dtype=np.uint8))) if (at_qual and ln) else b"I" * ln
+            rec = b"@r%d some comment\n" % i + seq(ln) + b"\n+" + (b"r%d" % i if plus_id and i % 3 == 0 else b"") + b"\n" + q + b"\n"
+            out.append(rec + (b"\n" if blank and i % 500 == 7 else b""))
+        data = b"".join(out)
+        if crlf:
+            data = data.replace(b"\n", b"\r\n")
+        if no_final_nl:
+            data = data.rstrip(b"\r\n")
+        return data[:len(data) - trunc] if trunc else data
+
+    def fa(n, width, crlf=False):
+        out = []
+        for i in range(n):
+            s = seq(int(rng.integers(1, 3000)))
+            out.append(b">c%d desc\n" % i + b"\n".join(s[j:j + width] for j in range(0, len(s), width)) + b"\n")
+        data = b"".join(out)
+        return data.replace(b"\n", b"\r\n") if crlf else data
+
+    n = 50_000  # ~ 20 MB: several 4 MB chunks per file
+    files = {"plain.fq": (fq(n), True), "crlf.fq": (fq(n, crlf=True), True), "plus.fq": (fq(n, plus_id=True), True),
+             "atq.fq": (fq(n, at_qual=True), True), "blank.fq": (fq(n, blank=True), True), "empty.fq": (fq(n, empty=True), True),
+             "nofinal.fq": (fq(n, no_final_nl=True), True), "trunc1.fq": (fq(2000, trunc=1), True),
+             "trunc5.fq": (fq(2000, trunc=5), False), "trunc200.fq": (fq(2000, trunc=200), False),
+             "multi.fa": (fa(8000, 60), True), "multicrlf.fa": (fa(8000, 60, crlf=True), True), "w1.fa": (fa(800, 1), True),
+             "garbage.fq": (b"@" + bytes(rng.integers(0, 256, 3_000_000, dtype=np.uint8)), False),
+             "onlyat.fq": (b"@\n" * 50_000, False), "tiny.fq": (b"@a\nA\n+\nI", True)}
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for name, (data, ok) in files.items():
+        path = tmp_path / name
+        path.write_bytes(data)
+        for t in (1, 5):
+            r = subprocess.run([str(exe), "bench-parse", str(path), "-t", str(t)], capture_output=True, text=True, env=env, timeout=300)
+            report = r.stdout + r.stderr
+            assert "AddressSanitizer" not in report and "runtime error" not in report, (name, t, report[-3000:])
+            if ok:
+                assert r.returncode == 0 and "parsed" in r.stdout, (name, t, report[-500:])
+            else:
+                assert r.returncode == 1 and "Error:" in r.stderr, (name, t, report[-500:])

@@ -560,34 +560,54 @@ def run_host_path(index, batches, params, oidx, cores, calls=6, reads_per_call=1
     one host's memory and PCIe root complexes, which is what the per-rank and summed rates show."""
     n_reads = min(batches[0].n_reads, reads_per_call)
     n_bases = n_reads * READ_LEN
-    host = [b.d_bases[:n_bases].cpu().numpy() for b in batches]
-    off = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(READ_LEN)
-    n_chk = min(200_000, n_reads)
-    if oidx is not None:
-        want = [oracle_decisions(oidx, h[:n_chk * READ_LEN], off[:n_chk + 1], None, params, cores)[0] for h in host]
-        checked = f"first {n_chk} reads of each of the {len(host)} batches vs the CPU oracle"
-    else:
-        n_chk = n_reads
-        want = [b.d_keep[:n_reads].cpu().numpy().astype(bool) for b in batches]
-        checked = f"all {n_reads} reads of each of the {len(host)} batches vs the device-resident run of the same batch"
-    proc = dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"], deplete=params["deplete"],
-                               max_batch_bases=n_bases, max_batch_reads=n_reads)
     G = (n_bases + 31) // 32
-    pins = []
-    t0 = time.time()
-    for h in host:
-        pb = dcn.PinnedBuffer(n_bases, np.uint8) if "pinned" in kinds else None
-        if pb is not None:
-            pb.array[:] = h
-        pp, pm = dcn.PinnedBuffer(2 * G, np.uint32), dcn.PinnedBuffer(G, np.uint32)
-        pins.append((pb, pp, pm))
-    tp = time.time()
-    for h, (pb, pp, pm) in zip(host, pins):
-        dcn._native.check(dcn._native.lib().dcn_pack_ascii(h.ctypes.data, n_bases, pp.array.ctypes.data, pm.array.ctypes.data, None))
-    pack_s = (time.time() - tp) / len(host)
-    poff = dcn.PinnedBuffer(n_reads + 1, np.uint64)
-    poff.array[:] = off
-    keeps = [dcn.PinnedBuffer(n_reads, np.uint8) for _ in range(2)]
+
+    def setup():
+        """everything that can fail for lack of memory (three batches on the host, page-locked copies, the context)"""
+        host = [b.d_bases[:n_bases].cpu().numpy() for b in batches]
+        off = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(READ_LEN)
+        n_chk = min(200_000, n_reads)
+        if oidx is not None:
+            want = [oracle_decisions(oidx, h[:n_chk * READ_LEN], off[:n_chk + 1], None, params, cores)[0] for h in host]
+            checked = f"first {n_chk} reads of each of the {len(host)} batches vs the CPU oracle"
+        else:
+            n_chk = n_reads
+            want = [b.d_keep[:n_reads].cpu().numpy().astype(bool) for b in batches]
+            checked = f"all {n_reads} reads of each of the {len(host)} batches vs the device-resident run of the same batch"
+        proc = dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"], deplete=params["deplete"],
+                                   max_batch_bases=n_bases, max_batch_reads=n_reads)
+        pins = []
+        t0 = time.time()
+        for h in host:
+            pb = dcn.PinnedBuffer(n_bases, np.uint8) if "pinned" in kinds else None
+            if pb is not None:
+                pb.array[:] = h
+            pp, pm = dcn.PinnedBuffer(2 * G, np.uint32), dcn.PinnedBuffer(G, np.uint32)
+            pins.append((pb, pp, pm))
+        tp = time.time()
+        for h, (pb, pp, pm) in zip(host, pins):
+            dcn._native.check(dcn._native.lib().dcn_pack_ascii(h.ctypes.data, n_bases, pp.array.ctypes.data, pm.array.ctypes.data, None))
+        pack_s = (time.time() - tp) / len(host)
+        poff = dcn.PinnedBuffer(n_reads + 1, np.uint64)
+        poff.array[:] = off
+        keeps = [dcn.PinnedBuffer(n_reads, np.uint8) for _ in range(2)]
+        return host, off, n_chk, want, checked, proc, pins, pack_s, poff, keeps, t0
+
+    # At N > 1 the ranks meet at barriers inside this leg: a rank that failed to set up must not leave the others waiting.
+    # Every rank learns whether all of them are ready, and the leg runs on all of them or on none.
+    st, err = None, None
+    try:
+        st = setup()
+    except Exception as ex:
+        err = repr(ex)
+    if world > 1:
+        ready = torch.tensor([0 if err else 1], dtype=torch.int64, device=coll_device)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if int(ready.item()) == 0:
+            return {"error": f"set-up failed on some rank ({err or 'not this one'}): the leg was skipped on every rank"}
+    elif err:
+        raise RuntimeError(err)
+    host, off, n_chk, want, checked, proc, pins, pack_s, poff, keeps, t0 = st
     log(f"host_path: buffers ready in {time.time() - t0:.1f} s; dcn_pack_ascii {n_bases / pack_s / 1e9:.1f} Gbp/s on the host threads")
     out = {"reads_per_call": n_reads, "bases_per_call": n_bases, "calls": calls, "repetitions": reps,
            "host_pack_Gbp_per_s": n_bases / pack_s / 1e9, "checked": checked,

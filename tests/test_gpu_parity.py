@@ -94,6 +94,20 @@ def test_table_membership(dcn):
     assert only_zero.n_keys == 1 and only_zero.contains(np.array([0, 1], np.uint64)).tolist() == [True, False]
 
 
+def test_probe_ceiling_measurement(dcn):
+    """dcn_index_probe_ceiling (measurement only): a positive rate for generated and for replayed key streams, nothing
+    for an empty request, and no effect on the set."""
+    import torch
+    keys = np.unique(np.random.default_rng(8).integers(1, 2**62, 200_000, dtype=np.uint64))
+    idx = dcn.Index.from_keys(keys, 31, 15)
+    assert idx.probe_ceiling(None, 1 << 20, reps=1) > 1e8
+    d = torch.from_numpy(keys.view(np.int64)).cuda()
+    assert idx.probe_ceiling(d.data_ptr(), d.numel(), reps=2) > 1e8
+    assert idx.probe_ceiling(None, 0, reps=1) == 0.0
+    assert idx.contains(keys[:1000]).all() and len(idx) == len(keys)
+    idx.close()
+
+
 def test_table_adversarial_keys(dcn):
     # keys that collide in the low / high bits must still be exact
     a = (np.arange(1, 50_001, dtype=np.uint64) << np.uint64(40))

@@ -1432,7 +1432,7 @@ int run_filter(const FilterArgs &a) {
         // >= any formatted size (renamed ids: <= 20 digits)
         if (mapped_out.open(a.output, 5 * (split_mapped ? in1 : in1 + in2) + (1u << 20)) && split_mapped &&
             !mapped_out2.open(a.output2, 5 * in2 + (1u << 20)))
-            die("Failed to map the second output file: " + a.output2 + " (DCN_CLI_NO_MMAP_OUT=1 writes through write(2))");
+            mapped_out.finish(0);  // both files through mappings, or both through write(2) (the file is re-created below)
     }
     const bool map_out = mapped_out.active();
     const bool map_out2 = map_out && mapped_out2.active();

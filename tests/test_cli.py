@@ -585,6 +585,9 @@ def test_paired_files_in_parallel_match_the_record_reader(tmp_path, monkeypatch)
         monkeypatch.delenv("DCN_CLI_NO_MMAP_OUT")
         assert [(tmp_path / "w1.fq").read_bytes(), (tmp_path / "w2.fq").read_bytes()] == outs["pool"][2:4], extra
         assert outs["pool"][2].count(b"\n") == outs["pool"][3].count(b"\n") > 0 or extra == ["-d"]  # mate for mate
+        # a second output that cannot be mapped (not a regular file) sends BOTH through write(2): same first file
+        run("filter", idx, r1, r2, "-t", 5, "-o", tmp_path / "n1.fq", "-O", "/dev/null", *extra)
+        assert (tmp_path / "n1.fq").read_bytes() == outs["pool"][2], extra
     # a file of mates that ends early, or runs on, is an error either way
     r2.write_bytes(b"".join(l2[:-3]))
     p = run("filter", idx, r1, r2, check=False)

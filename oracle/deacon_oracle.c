@@ -896,8 +896,9 @@ int dor_index_add_sequence(dor_set *set, const uint8_t *seq, uint64_t len, uint3
  * equal to the plain port on its sample before its time is reported.  Differences are purely
  * mechanical: one workspace per thread (no malloc per read), window minima by the prefix/suffix
  * ("two-stack") scheme over blocks of w keys instead of a rescan, rolling forward / reverse-
- * complement k-mer values, a seen-set with epoch tags instead of a fresh set per unit, and units
- * handed to threads in chunks from a shared cursor.  Still a restatement of
+ * complement k-mer values, a seen-set with epoch tags instead of a fresh set per unit, the
+ * index lookups of a unit prefetched ahead of their use, and units handed to threads in chunks
+ * from a shared cursor.  Still a restatement of
  * src/filter_common.rs:211-310 + :129-198 + :84-112, not of the crates' SIMD code.
  * ---------------------------------------------------------------------------------------- */
 typedef struct tuned_ws {
@@ -1085,8 +1086,13 @@ static uint64_t tuned_distinct_hits(tuned_ws *ws, const dor_set *index) {
     uint64_t mask = 15;
     while (mask + 1 < 2 * n + 2) mask = mask * 2 + 1;
     uint64_t hits = 0;
+    /* the index is far larger than the caches (8.6 GB for panhuman-1's size): a unit's home slots are requested ahead of
+     * the lookups, so that its ~14 (or thousands of) cache misses overlap instead of queueing one behind the other */
+    const uint64_t AHEAD = 16;
+    for (uint64_t q = 0; q < n && q < AHEAD; ++q) __builtin_prefetch(&index->slots[mix64(ws->hashes[q]) & index->mask]);
     for (uint64_t q = 0; q < n; ++q) {
         const uint64_t h = ws->hashes[q];
+        if (q + AHEAD < n) __builtin_prefetch(&index->slots[mix64(ws->hashes[q + AHEAD]) & index->mask]);
         if (!dor_set_contains(index, h)) continue;
         uint64_t i = mix64(h) & mask;
         for (;;) {

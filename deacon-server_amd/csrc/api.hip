@@ -677,6 +677,9 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     da.status = c->d_status;
     da.caps = c->d_caps;
     da.big = c->d_big;
+    da.g_total = (!v.d_hits && !v.d_total && !getenv("DCN_NO_EARLY_OUT")) ? g_total : nullptr;
+    da.abs_threshold = params->abs_threshold;
+    da.rel_threshold = params->rel_threshold;
     DCN_TRY(dcn_launch_distinct(da, st));
     DCN_PROF_MARK(DCN_STAGE_DISTINCT);
 
@@ -1907,6 +1910,9 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         da.status = c->d_status;
         da.caps = c->d_caps;
         da.big = c->d_big;
+        da.g_total = nullptr; // (the server's answer carries the hit count: src/server_common.rs:54-58)
+        da.abs_threshold = params->abs_threshold;
+        da.rel_threshold = params->rel_threshold;
         DCN_TRY(dcn_launch_distinct(da, st));
         dcn_finish_args fa;
         fa.n_units = n_units;

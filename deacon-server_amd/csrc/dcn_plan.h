@@ -44,6 +44,11 @@ struct dcn_distinct_args {
     uint64_t set_capacity;
     uint32_t n_units;
     dcn_status *status;
+    // decisions only (the caller takes neither hit counts nor totals, src/local_filter.rs:350-371): a unit's count may stop
+    // at the hits its decision needs.  g_total is complete when this pass runs, so `required` is known per unit.
+    const uint32_t *g_total; // null: count everything
+    uint64_t abs_threshold;
+    double rel_threshold;
 };
 
 struct dcn_finish_args {

@@ -204,24 +204,43 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
     const uint32_t NP = a.status->n_pending;
     const uint32_t lane = threadIdx.x;
     // the next unit's descriptor is fetched while this one is counted
-    uint32_t nu = 0, nfirst = 0, ncount = 0, nH = 0;
+    uint32_t nu = 0, nfirst = 0, ncount = 0, nH = 0, ntot = 0;
     auto fetch = [&](uint32_t i) {
         if (i < NP) {
             nu = a.pending[i];
             nfirst = a.unit_tile_first[nu];
             ncount = a.unit_tile_count[nu];
             nH = a.g_hitcnt[nu];
+            ntot = a.g_total ? a.g_total[nu] : 0u;
         }
     };
     fetch(blockIdx.x);
     for (uint32_t i = blockIdx.x; i < NP; i += gridDim.x) {
-        const uint32_t u = nu, first = nfirst, count = ncount, H = nH;
+        const uint32_t u = nu, first = nfirst, count = ncount, H = nH, tot = ntot;
         fetch(i + gridDim.x);
         if (H == 0) {
             if (lane == 0) a.caps[u] = 0;
             continue;
         }
-        if (count == 0xFFFFFFFFu || H > DCN_LDS_SET_MAX || count > DCN_LDS_WALK_MAX_TILES) {
+        // Decisions only: the unit is kept or dropped by `distinct hits >= required`, and required is known now (the scan
+        // has finished, so the unit's minimizer total is complete).  Fewer hits than required, duplicates or not: decided,
+        // nothing to count.  Otherwise the count may stop as soon as it reaches required -- a read of the indexed genome has
+        // hundreds of hits and needs a dozen.  (Counting mode reports the exact number and takes neither shortcut.)
+        uint32_t enough = 0xFFFFFFFFu;
+        if (a.g_total) {
+            const uint64_t req = dcn_required_hits(a.abs_threshold, a.rel_threshold, tot);
+            if ((uint64_t)H < req) {
+                if (lane == 0) {
+                    a.g_distinct[u] = 0; // any value below `required` gives the same decision
+                    a.caps[u] = 0;
+                }
+                continue;
+            }
+            enough = req > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)req;
+        }
+        // (a count that may stop at `enough` never holds more than that many keys: the LDS set serves units of any hit count then)
+        const uint32_t Hset = H < enough ? H : enough;
+        if (count == 0xFFFFFFFFu || Hset > DCN_LDS_SET_MAX || count > DCN_LDS_WALK_MAX_TILES) {
             // global set: a power-of-two region of >= 2x the hit count, handed out from one cursor (all regions are
             // cleared by one small kernel between the passes)
             uint32_t cap = 64;
@@ -247,7 +266,7 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
             continue;
         }
         uint32_t cap = 64;
-        while (cap < 2u * H) cap <<= 1;
+        while (cap < 2u * Hset && cap < DCN_LDS_SET_SLOTS) cap <<= 1;
         if (cap > DCN_LDS_SET_SLOTS) cap = DCN_LDS_SET_SLOTS;
         // the unit's first 64 tiles (usually all of them): both loads in flight while the set is cleared
         auto tile_run = [&](uint32_t t, uint32_t &n, uint64_t &slot0) {
@@ -265,15 +284,15 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
         for (uint32_t q = lane; q < cap; q += 64) set[q] = 0;
         __syncthreads();
         uint32_t distinct = 0;
-        for (uint32_t t0 = 0; t0 < count; t0 += 64) {
+        for (uint32_t t0 = 0; t0 < count && distinct < enough; t0 += 64) {
             if (t0) tile_run(t0 + lane, n, slot0);
             unsigned long long runs = __ballot(n != 0);
-            while (runs) { // one or two per unit: a run per wave that held tiles of it
+            while (runs && distinct < enough) { // one or two per unit: a run per wave that held tiles of it
                 const int r = __ffsll((long long)runs) - 1;
                 runs &= runs - 1;
                 const uint32_t rn = __shfl(n, r, 64);
                 const uint64_t rs = (uint64_t)__shfl((long long)slot0, r, 64);
-                for (uint32_t j0 = 0; j0 < rn; j0 += 256) { // four loads in flight per lane
+                for (uint32_t j0 = 0; j0 < rn && distinct < enough; j0 += 256) { // four loads in flight per lane
                     uint64_t h[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

@@ -28,6 +28,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #define DOR_OK 0
 #define DOR_ERR_ARG (-1)
@@ -456,12 +457,29 @@ static inline uint64_t mix64(uint64_t x) {
     return x;
 }
 
+/* zeroed table; large ones on 2 MB-aligned memory with transparent huge pages requested: a probe of a multi-GB table is a
+ * TLB miss on 4 KB pages before it is a cache miss (free() releases both kinds) */
+static uint64_t *table_alloc(uint64_t cap) {
+    const size_t bytes = (size_t)cap * sizeof(uint64_t);
+    if (bytes >= ((size_t)64 << 20)) {
+        void *p = NULL;
+        if (posix_memalign(&p, (size_t)2 << 20, bytes) == 0 && p) {
+#ifdef MADV_HUGEPAGE
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+            memset(p, 0, bytes);
+            return (uint64_t *)p;
+        }
+    }
+    return (uint64_t *)calloc(cap, sizeof(uint64_t));
+}
+
 dor_set *dor_set_new(uint64_t expected) {
     dor_set *s = (dor_set *)calloc(1, sizeof(dor_set));
     if (!s) return NULL;
     uint64_t cap = 16;
     while (cap < expected * 2 + 2) cap <<= 1;
-    s->slots = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    s->slots = table_alloc(cap);
     if (!s->slots) {
         free(s);
         return NULL;
@@ -505,7 +523,7 @@ int dor_set_insert(dor_set *s, uint64_t key) {
 static int dor_set_grow(dor_set *s) {
     uint64_t old_cap = s->mask + 1, new_cap = old_cap * 2;
     uint64_t *old = s->slots;
-    uint64_t *neu = (uint64_t *)calloc(new_cap, sizeof(uint64_t));
+    uint64_t *neu = table_alloc(new_cap);
     if (!neu) return DOR_ERR_NOMEM;
     s->slots = neu;
     s->mask = new_cap - 1;
@@ -584,7 +602,7 @@ int dor_set_insert_many_mt(dor_set *s, const uint64_t *keys, uint64_t n, int n_t
     if (s->mask + 1 < need) {
         uint64_t cap = s->mask + 1;
         while (cap < need) cap <<= 1;
-        uint64_t *neu = (uint64_t *)calloc(cap, sizeof(uint64_t));
+        uint64_t *neu = table_alloc(cap);
         if (!neu) return DOR_ERR_NOMEM;
         uint64_t *old = s->slots, old_cap = s->mask + 1;
         s->slots = neu;

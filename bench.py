@@ -412,7 +412,7 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
         # not the headline: same batches, same K steps, caller passes no hits/total arrays (what the CLI does outside
         # --debug); reads whose decision is fixed after abs_threshold distinct hits are not probed further
         "decisions_only": {"value": bases_done * world / elapsed2 / 1e6, "unit": "Mbp/s", "ms_per_step": elapsed2 / steps * 1e3,
-                           "scan_ms_per_launch": stage2["scan"],
+                           "scan_ms_per_launch": stage2["scan"], "stage_ms_per_launch": stage2,
                            "decisions_identical_to_counting_mode": all(bool(torch.equal(b.d_keep, b.d_keep2)) for b in batches[:min(len(batches), steps)])},
     }
     return res, counters, elapsed, bases_done

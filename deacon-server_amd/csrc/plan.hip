@@ -265,9 +265,10 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
                 for (uint32_t q = lane; q < n_items; q += 64) a.big[item0 + q] = make_uint2(u, 64 * q);
             continue;
         }
+        // (the stop is tested once per 256 entries: up to 255 keys beyond `enough` may have gone in by then)
+        const uint32_t most = enough == 0xFFFFFFFFu ? Hset : (Hset + 256u < H ? Hset + 256u : H);
         uint32_t cap = 64;
-        while (cap < 2u * Hset && cap < DCN_LDS_SET_SLOTS) cap <<= 1;
-        if (cap > DCN_LDS_SET_SLOTS) cap = DCN_LDS_SET_SLOTS;
+        while (cap < 2u * most && cap < DCN_LDS_SET_SLOTS) cap <<= 1;
         // the unit's first 64 tiles (usually all of them): both loads in flight while the set is cleared
         auto tile_run = [&](uint32_t t, uint32_t &n, uint64_t &slot0) {
             n = 0;

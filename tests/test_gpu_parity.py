@@ -610,6 +610,50 @@ def test_properties_at_scale(oracle, dcn, genome, index_pair):
     assert want[1].tolist() == hits[sl].tolist() and want[2].tolist() == total[sl].tolist()
 
 
+def test_mixed_long_and_short_stream_properties(oracle, dcn, genome, index_pair, monkeypatch):
+    """BASELINE configs[4]'s stream shape: long and short reads interleaved in one batch without unit ids.  The planner
+    puts the tiles of multi-tile reads ahead of the single-tile reads inside each planning block (round 3), so the tile
+    order is no longer the read order: per-read results must not notice -- equal to filtering the long and the short
+    reads as two separate batches, equal for another tile size, equal in decisions-only mode, and (on a slice) equal to
+    the oracle."""
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(61)
+    reads, is_long = [], []
+    while sum(len(r) for r in reads) < 40_000_000:
+        ln = int(min(150_000, max(300, rng.lognormal(8.9, 0.8))))
+        if rng.random() < 0.5:
+            s = int(rng.integers(0, len(genome) - 1)) % max(1, len(genome) - ln) if ln < len(genome) else 0
+            seg = (genome * (ln // len(genome) + 2))[s:s + ln]
+            reads.append(mutate(rng, seg, 0.05))
+        else:
+            reads.append(random_reads(rng, 1, ln, ln)[0])
+        is_long.append(True)
+        short = sample_reads(rng, genome, max(1, ln // 150), 150, 150)
+        reads += short
+        is_long += [False] * len(short)
+    is_long = np.array(is_long)
+    b, o = oracle.concat_reads(reads)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=len(b) + 64, max_batch_reads=len(reads) + 1)
+    keep, hits, total = proc.filter_batch(b, o)
+    assert keep[is_long].any() and keep[~is_long].any() and (~keep)[is_long].any()
+    # the two kinds as separate batches
+    for sel in (is_long, ~is_long):
+        sub = [r for r, f in zip(reads, sel) if f]
+        sb, so = oracle.concat_reads(sub)
+        k2, h2, t2 = proc.filter_batch(sb, so)
+        assert (k2 == keep[sel]).all() and (h2 == hits[sel]).all() and (t2 == total[sel]).all()
+    assert (proc.filter_batch(b, o, counts=False) == keep).all()          # decisions only (the distinct pass may stop early)
+    proc.close()
+    monkeypatch.setenv("DCN_TILE_WINDOWS", "64")                           # many more multi-tile reads, other wave seams
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=len(b) + 64, max_batch_reads=len(reads) + 1)
+    k3, h3, t3 = proc.filter_batch(b, o)
+    assert (k3 == keep).all() and (h3 == hits).all() and (t3 == total).all()
+    proc.close()
+    n = int(np.searchsorted(o, 3_000_000))
+    want = oracle.filter_batch(oidx, b[:int(o[n])], o[:n + 1], threads=4)
+    assert want[0].tolist() == keep[:n].tolist() and want[1].tolist() == hits[:n].tolist() and want[2].tolist() == total[:n].tolist()
+
+
 def test_units_of_many_reads_cut_by_a_planning_block(oracle, dcn, genome, index_pair):
     """unit_id may group any number of consecutive reads.  A unit whose reads fall into two planning blocks (256 reads
     each) has no contiguous tile range: the scan cannot finish it in-wave, and the distinct pass finds its tiles by

@@ -27,7 +27,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#define DCN_VERSION_STRING "deacon-hip 0.2.0 (gfx950)"
+#define DCN_VERSION_STRING "deacon-hip 0.3.0 (gfx950)"
 
 // ----------------------------------------------------------------------------------------------------
 // errors

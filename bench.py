@@ -440,6 +440,51 @@ def committed_traffic(rf, workload, bases_per_batch, index_keys, host_genome):
     return None
 
 
+def live_traffic(workload, reads, index_keys, host_genome):
+    """HBM bytes per launch of the counting scan kernel, MEASURED in this run: two child runs of this same file under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: separate passes, counters only -- no tracing domain beside them), same
+    workload, three timed steps each.  Calibration as profiles/r02_traffic.json: for this kernel's scattered 16-byte reads
+    the counter x 1024 B reproduces the sector bytes (no x2).  None when rocprofv3 is not at hand or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = {}
+    d = tempfile.mkdtemp(prefix="dcn_pmc_", dir="/tmp")
+    try:
+        for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE", "TCC_HIT", "TCC_MISS"])):
+            od = os.path.join(d, name)
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", od, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--workload", workload, "--reads", str(reads),
+                   "--index-keys", str(index_keys), "--host-genome", str(host_genome)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if p.returncode != 0:
+                log(f"live PMC pass '{name}' failed ({p.returncode}): {p.stderr[-300:]}")
+                return None
+            acc = {}
+            for path in glob.glob(os.path.join(od, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if "scan_kernel<15, false, false, false" in r["Kernel_Name"]:
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for k_, v in acc.items():
+                out[k_] = sum(v) / len(v)
+                out["dispatches"] = len(v)
+        if "FETCH_SIZE" not in out or "WRITE_SIZE" not in out:
+            return None
+        out["hbm_bytes_per_launch"] = (out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0
+        return out
+    except Exception as ex:
+        log(f"live PMC passes failed: {ex!r}")
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def probe_only_rate(index, device, n=64_000_000, reps=5):
     """The library's own set-membership kernel (dcn_index_contains_device: one 16-byte group read per key, nothing else)
     on n uniformly random keys against the SAME table: the scattered-request rate this box gives this table now.
@@ -729,7 +774,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other configs and the host-path measurements that follow the headline at N = 1")
-    ap.add_argument("--extras", default="long,paired,host_path,cli,host1g,host95,union950m",
+    ap.add_argument("--extras", default="long,paired,host_path,cli,pmc,host1g,host95,union950m",
                     help="which of the extra measurements to run (comma separated)")
     args = ap.parse_args()
 
@@ -909,6 +954,21 @@ def main():
                     if short_batches is None:
                         short_batches = make_batches("short", genome_dev, args.reads, seeds["short"], device)
                     host_path = run_host_path(index, short_batches, P_SHORT, oidx, cores, reads_per_call=args.reads)
+                elif e == "pmc":
+                    # roofline.traffic measured in THIS run (it used to be read from a committed file only):
+                    # child runs of this file under rocprofv3 --pmc, on the same GPU, after the timed region
+                    lt = live_traffic(args.workload, args.reads, args.index_keys, args.host_genome)
+                    if lt:
+                        rf_ = out["roofline"]
+                        rf_["traffic_committed"] = {"bytes": rf_.get("traffic"), "source": rf_.get("traffic_source")}
+                        rf_["traffic"] = lt["hbm_bytes_per_launch"]
+                        rf_["traffic_source"] = ("live: two child runs of this bench under `rocprofv3 --pmc` (FETCH_SIZE; WRITE_SIZE TCC_HIT TCC_MISS), "
+                                                 f"mean over {lt['dispatches']} dispatches of the counting scan kernel")
+                        rf_["traffic_counters"] = {k_: lt[k_] for k_ in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT", "TCC_MISS") if k_ in lt}
+                        rf_["traffic_rate_GBps"] = rf_["traffic"] / (rf_["avg_launch_ms"] * 1e-3) / 1e9
+                        rf_["traffic_frac_of_peak"] = rf_["traffic_rate_GBps"] / HBM_PEAK_GBS
+                        log(f"live PMC: {rf_['traffic'] / 1e9:.2f} GB per scan launch ({rf_['traffic'] / rf_['algorithmic_bytes_per_launch']:.2f} x algorithmic), "
+                            f"{time.time() - t_e:.0f} s")
                 elif e == "cli":
                     # `deacon-hip` file to file, as a user runs it (bench_cli.py): configs[0] at its stated shape, then
                     # search / host depletion / two files of mates against this index written as an index FILE

@@ -13,7 +13,8 @@ half are random.  Weak scaling: every rank holds a full index replica and filter
 collective is the all-reduce of the six summary counters (RCCL) at the end of the timed region.
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job Mbp/s of that workload, plus
-  roofline      dominant kernel (scan): algorithmic HBM bytes / HIP-event time on the kernel's own stream
+  roofline      dominant kernel (scan): algorithmic HBM bytes / HIP-event time on the kernel's own stream; `traffic` = HBM bytes
+                per launch from PMC counters, measured after the timed region by child runs of this file under rocprofv3 --pmc
   cpu_baseline  the CPU oracle (oracle/, "port") on a bounded sample of the same reads, all host cores
 and, at N = 1 (after the timed region; none of it enters `value`):
   workloads.{long,paired,union950m,host1g,host95}   BASELINE configs[2], [3], [4]-sized table, and a >= 1 Gbp host genome

@@ -463,7 +463,7 @@ def live_traffic(workload, reads, index_keys, host_genome):
                    "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--workload", workload, "--reads", str(reads),
                    "--index-keys", str(index_keys), "--host-genome", str(host_genome)]
             env = dict(os.environ, TMPDIR="/tmp")
-            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             if p.returncode != 0:
                 log(f"live PMC pass '{name}' failed ({p.returncode}): {p.stderr[-300:]}")
                 return None

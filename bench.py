@@ -486,6 +486,20 @@ def live_traffic(workload, reads, index_keys, host_genome):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def apply_live_traffic(rf, lt):
+    """put a live_traffic() result into a roofline block (the committed figure, if any, stays beside it)"""
+    if not lt:
+        return False
+    rf["traffic_committed"] = {"bytes": rf.get("traffic"), "source": rf.get("traffic_source")}
+    rf["traffic"] = lt["hbm_bytes_per_launch"]
+    rf["traffic_source"] = ("live: two child runs of this bench under `rocprofv3 --pmc` (FETCH_SIZE; WRITE_SIZE TCC_HIT TCC_MISS), "
+                            f"mean over {lt['dispatches']} dispatches of the counting scan kernel")
+    rf["traffic_counters"] = {k_: lt[k_] for k_ in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT", "TCC_MISS") if k_ in lt}
+    rf["traffic_rate_GBps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+    rf["traffic_frac_of_peak"] = rf["traffic_rate_GBps"] / HBM_PEAK_GBS
+    return True
+
+
 def probe_only_rate(index, device, n=64_000_000, reps=5):
     """The library's own set-membership kernel (dcn_index_contains_device: one 16-byte group read per key, nothing else)
     on n uniformly random keys against the SAME table: the scattered-request rate this box gives this table now.
@@ -947,6 +961,8 @@ def main():
                     r["decisions_match_gpu"], r["oracle_sample"] = ok, what + f" vs the oracle's {len(oidx):,}-key set (keep, hits, totals)"
                     r["workload"] = names[e]
                     committed_traffic(r["roofline"], e, bs[0].n_bases, int(index.n_keys), args.host_genome)
+                    if "pmc" in extras:  # ... and measured in this run as well (the same batches: same generator, same seed)
+                        apply_live_traffic(r["roofline"], live_traffic(e, args.reads, args.index_keys, args.host_genome))
                     workloads[e] = r
                     del bs
                     log(f"workloads.{e}: {r['value'] / 1e3:.1f} Gbp/s counting, {r['decisions_only']['value'] / 1e3:.1f} Gbp/s decisions only, "
@@ -959,15 +975,8 @@ def main():
                     # roofline.traffic measured in THIS run (it used to be read from a committed file only):
                     # child runs of this file under rocprofv3 --pmc, on the same GPU, after the timed region
                     lt = live_traffic(args.workload, args.reads, args.index_keys, args.host_genome)
-                    if lt:
+                    if apply_live_traffic(out["roofline"], lt):
                         rf_ = out["roofline"]
-                        rf_["traffic_committed"] = {"bytes": rf_.get("traffic"), "source": rf_.get("traffic_source")}
-                        rf_["traffic"] = lt["hbm_bytes_per_launch"]
-                        rf_["traffic_source"] = ("live: two child runs of this bench under `rocprofv3 --pmc` (FETCH_SIZE; WRITE_SIZE TCC_HIT TCC_MISS), "
-                                                 f"mean over {lt['dispatches']} dispatches of the counting scan kernel")
-                        rf_["traffic_counters"] = {k_: lt[k_] for k_ in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT", "TCC_MISS") if k_ in lt}
-                        rf_["traffic_rate_GBps"] = rf_["traffic"] / (rf_["avg_launch_ms"] * 1e-3) / 1e9
-                        rf_["traffic_frac_of_peak"] = rf_["traffic_rate_GBps"] / HBM_PEAK_GBS
                         log(f"live PMC: {rf_['traffic'] / 1e9:.2f} GB per scan launch ({rf_['traffic'] / rf_['algorithmic_bytes_per_launch']:.2f} x algorithmic), "
                             f"{time.time() - t_e:.0f} s")
                 elif e == "cli":
@@ -1063,6 +1072,8 @@ def main():
                         r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB); {shape}"
                         if kind_ == "mixed":
                             committed_traffic(r["roofline"], "mixed", bs[0].n_bases, int(idx3.n_keys), args.host_genome)
+                            if "pmc" in extras:  # (the child draws its own mixed batches: same generator, another seed)
+                                apply_live_traffic(r["roofline"], live_traffic("mixed", args.reads, UNION_KEYS, args.host_genome))
                         r["table_build_s"] = tb
                         workloads[key_] = r
                         del bs

@@ -391,6 +391,7 @@ struct dcn_ctx {
     // hit runs of the units the scan does not finish (one slot per base, see scan.hip) + global sets of the few
     // units whose hits do not fit the LDS set of the distinct pass (4 slots per record of capacity)
     uint64_t *d_rec_hash = nullptr;
+    uint32_t rec_shift = 0;      // one slot of d_rec_hash per 2^rec_shift bases (dcn_scan_args::rec_shift)
     char *d_slab = nullptr;      // DCN_CTX_SLAB: one allocation behind the fixed-size buffers above
     uint64_t slab_bytes = 0;
     uint32_t *d_tile_hits = nullptr, *d_pending = nullptr;
@@ -651,6 +652,8 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     sa.g_hitcnt = g_hitcnt;
     sa.g_zero = g_zero;
     sa.rec_hash = c->d_rec_hash;
+    sa.rec_shift = c->rec_shift;
+    sa.tile_windows = c->tile_windows;
     sa.tile_hits = c->d_tile_hits;
     sa.pending = c->d_pending;
     sa.status = c->d_status;
@@ -668,6 +671,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     da.tile_hits = c->d_tile_hits;
     da.pending = c->d_pending;
     da.rec_hash = c->d_rec_hash;
+    da.rec_shift = c->rec_shift;
     da.g_hitcnt = g_hitcnt;
     da.g_distinct = g_distinct;
     da.set_off = c->d_set_off;
@@ -707,6 +711,19 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     return DCN_OK;
 }
 
+// a run overflowed (dcn_status::run_overflow): from now on the context keeps one slot of the record array per window
+int grow_run_slots(dcn_ctx *c) {
+    // (a batch that was in flight beside the one that made the context switch over reports the same overflow, from its
+    // run under the old geometry: it is simply run again)
+    if (c->rec_shift == 0) return DCN_OK;
+    uint64_t *neu = nullptr;
+    DCN_TRY(dev_alloc(&neu, c->max_bases + 128, "rec_hash (one slot per window)"));
+    if (c->d_rec_hash && !((char *)c->d_rec_hash >= c->d_slab && (char *)c->d_rec_hash < c->d_slab + c->slab_bytes)) hipFree(c->d_rec_hash);
+    c->d_rec_hash = neu;
+    c->rec_shift = 0;
+    return DCN_OK;
+}
+
 int overflow_error(const dcn_ctx *c, uint64_t need) {
     return dcn_fail(DCN_ERR_CAPACITY, "hit-record scratch overflow: need " + std::to_string(need) +
                                           " records, have " + std::to_string(c->rec_capacity) +
@@ -729,8 +746,13 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     }
     if (c->h_report->overflow) {
         const uint64_t need = c->h_report->need;
+        const bool runs = (c->h_report->overflow & 2u) != 0, sets = (c->h_report->overflow & 1u) != 0;
         DCN_HIP(hipMemsetAsync(c->d_report, 0, offsetof(dcn_batch_report, stats), c->stream)); // re-arm, ordered before the next batch
-        if (needed_records) *needed_records = need;
+        if (runs) DCN_TRY(grow_run_slots(c)); // (the stream is idle: nothing reads the old array any more)
+        if (needed_records) *needed_records = sets ? need : 0;
+        if (!sets)
+            return dcn_fail(DCN_ERR_CAPACITY, "a unit had more hits in one wave than its run of the record array holds; the context "
+                                              "now keeps one slot per window: enqueue the batches since the last synchronize again");
         return overflow_error(c, need);
     }
     return DCN_OK;
@@ -1037,6 +1059,11 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
         ok = hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_comp[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) return fail(dcn_fail(DCN_ERR_HIP, "stream/event creation failed"));
+    // Runs of the record array: one slot per four windows (2 B per base of the batch instead of 8).  A unit would need a hit
+    // in more than every fourth window of a wave to fill its run -- real sequence has a minimizer in every eighth -- and a
+    // batch that does (w = 1, say) is run again with one slot per window (grow_run_slots).  DCN_REC_SHIFT = 0..3 fixes it.
+    c->rec_shift = 2;
+    if (const char *rs = getenv("DCN_REC_SHIFT")) c->rec_shift = (uint32_t)std::min(3, std::max(0, atoi(rs)));
     uint64_t MR = max_batch_reads;
     // DCN_CTX_SLAB=1 (experiment, profiles/placement_order.py): the fixed-size buffers below come out of ONE allocation,
     // each on a 2 MB boundary, instead of 24 separate ones
@@ -1079,7 +1106,7 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     A(d_tile_hits, mt, "tile_hits");
     A(d_pending, MR, "pending");
     A(d_big, MR + mt / 64 + 1, "big");
-    A(d_rec_hash, max_batch_bases + 64, "rec_hash");
+    A(d_rec_hash, (max_batch_bases >> c->rec_shift) + 256, "rec_hash");
     A(d_status, 1, "status");
     A(d_report, 1, "report");
 #undef A
@@ -1562,10 +1589,14 @@ int wait_impl(dcn_ctx *c, uint64_t ticket) {
         // Some chunk dropped hit records.  Grow the scratch and run the batch's kernels again: its inputs are still
         // resident in the slot.  Everything else in flight is drained first, since the scratch is shared.
         const uint64_t need = sl.h_report->need;
-        if (attempt >= 3) return fail(overflow_error(c, need));
+        if (attempt >= 4) return fail(overflow_error(c, need));
         drain(c);
-        uint64_t want = std::max<uint64_t>(need + need / 8 + 1024, c->rec_capacity * 2);
-        int rc = alloc_records(c, std::min<uint64_t>(want, 1ull << 29));
+        int rc = DCN_OK;
+        if (sl.h_report->overflow & 2u) rc = grow_run_slots(c); // one slot per window from now on
+        if (rc == DCN_OK && (sl.h_report->overflow & 1u)) {
+            uint64_t want = std::max<uint64_t>(need + need / 8 + 1024, c->rec_capacity * 2);
+            rc = alloc_records(c, std::min<uint64_t>(want, 1ull << 29));
+        }
         if (rc != DCN_OK) return fail(rc);
         if (hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream) != hipSuccess)
             return fail(dcn_fail(DCN_ERR_HIP, "hipMemsetAsync failed"));
@@ -1901,6 +1932,7 @@ extern "C" int dcn_should_keep_hashes(dcn_ctx *ctx, const uint64_t *hashes, cons
         da.tile_hits = c->d_tile_hits;
         da.pending = c->d_pending;
         da.rec_hash = d_hashes;
+        da.rec_shift = 0;
         da.g_hitcnt = g_hitcnt;
         da.g_distinct = g_distinct;
         da.set_off = c->d_set_off;

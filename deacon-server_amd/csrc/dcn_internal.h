@@ -119,6 +119,7 @@ struct dcn_status {
     uint32_t n_pending;            // units enrolled for the distinct pass (scan.hip)
     uint32_t any_newline;          // the pack kernel saw a '\n' byte: only then does planning probe read ends
     uint32_t bounds;               // DCN_DEBUG_BOUNDS builds: phase B met an index outside its list / its stream
+    uint32_t run_overflow;         // a unit had more hits in one wave than its run of the record array holds (rec_shift > 0)
     unsigned long long set_cursor; // distinct pass: slots handed out to the global per-unit hash sets
 };
 
@@ -126,7 +127,8 @@ struct dcn_status {
 // device-pointer API.  Read back when the batch is waited for / the context is synchronised.
 struct dcn_batch_report {
     uint32_t overflow;                     // a chunk dropped hit records: its multi-wave units were decided from
-                                           // truncated records and its counters were skipped
+                                           // truncated records and its counters were skipped.  Bit 0: the global sets'
+                                           // scratch was too small; bit 1: a run of the record array was (rec_shift > 0)
     uint32_t bounds;                       // DCN_DEBUG_BOUNDS builds only: the scan kernel refused an out-of-range index
     unsigned long long need;               // record capacity (set slots / 4) that would have sufficed
     unsigned long long stats[DCN_N_STATS]; // the six ProcessingStats counters
@@ -160,7 +162,10 @@ struct dcn_scan_args {
     uint32_t *g_total;   // per unit, atomically accumulated
     uint32_t *g_hitcnt;  // per unit: hits written to its runs (one atomicAdd per wave holding tiles of the unit)
     uint32_t *g_zero;    // per unit: the zero hash was a hit
-    uint64_t *rec_hash;  // one slot per base of the batch stream; a run starts at scan_start + carry of its first tile
+    uint64_t *rec_hash;  // one slot per 2^rec_shift bases of the batch stream; a run starts at (scan_start + carry of its
+                         // first tile) >> rec_shift and holds as many hits as its unit's windows in this wave >> rec_shift
+    uint32_t rec_shift;
+    uint32_t tile_windows; // windows of a full tile (a shorter tile is its read's last)
     uint32_t *tile_hits; // per tile: length of the run that starts at this tile (0: none)
     uint32_t *pending;   // units the scan did not finish, in no particular order (status->n_pending of them)
     dcn_status *status;

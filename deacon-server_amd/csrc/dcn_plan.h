@@ -34,6 +34,7 @@ struct dcn_distinct_args {
     const uint8_t *unit_state;       // 1 = finished by the scan kernel
     const uint32_t *tile_hits;       // per tile: length of the run that starts at it
     const uint64_t *rec_hash;        // runs of hit hashes, 0 = no entry
+    uint32_t rec_shift;              // a run starts at slot (scan_start + carry of its first tile) >> rec_shift
     const uint32_t *pending;         // work list: status->n_pending units
     const uint32_t *g_hitcnt;        // per unit: total run length
     uint32_t *g_distinct;

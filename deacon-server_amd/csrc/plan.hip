@@ -201,6 +201,7 @@ __device__ inline uint32_t set_slot_of(uint64_t h, uint32_t cap) {
 
 __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) {
     __shared__ unsigned long long set[DCN_LDS_SET_SLOTS];
+    if (a.status->run_overflow) return; // a run was refused hits: the lengths no longer describe the runs, the batch is re-run
     const uint32_t NP = a.status->n_pending;
     const uint32_t lane = threadIdx.x;
     // the next unit's descriptor is fetched while this one is counted
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(64) void unit_distinct_kernel(dcn_distinct_args a) 
             if (t < count) {
                 n = a.tile_hits[first + t];
                 const dcn_tile tl = a.tiles[first + t];
-                slot0 = tl.scan_start + tl.carry();
+                slot0 = (tl.scan_start + tl.carry()) >> a.rec_shift;
             }
         };
         uint32_t n;
@@ -368,7 +369,7 @@ __device__ inline uint32_t insert_run(const uint64_t *rec_hash, uint64_t slot0, 
 }
 
 __global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots, uint64_t capacity, const dcn_status *status) {
-    if (status->set_cursor == 0 || status->rec_overflow) return;
+    if (status->set_cursor == 0 || status->rec_overflow || status->run_overflow) return;
     uint64_t total = status->set_cursor;
     if (total > capacity) total = capacity;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void distinct_clear_kernel(uint64_t *set_slots
 // more reads cut by a planning block's boundary: never a single read, never a pair of a batch made of pairs only (the
 // block size is even), but a pair CAN be cut when a batch mixes unit sizes (units of one and of two reads).
 __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
-    if (a.status->set_cursor == 0 || a.status->rec_overflow) return;
+    if (a.status->set_cursor == 0 || a.status->rec_overflow || a.status->run_overflow) return;
     const uint32_t NB = a.status->n_big;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
         if (t < count) {
             n = a.tile_hits[first + t];
             const dcn_tile tl = a.tiles[first + t];
-            slot0 = tl.scan_start + tl.carry();
+            slot0 = (tl.scan_start + tl.carry()) >> a.rec_shift;
         }
         uint32_t fresh_n = 0;
         unsigned long long runs = __ballot(n != 0);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void big_insert_kernel(dcn_distinct_args a) {
         const uint32_t cap = a.caps[tl.unit];
         const uint32_t n = a.tile_hits[t];
         if (!cap || !n) continue;
-        const uint32_t fresh_n = insert_run(a.rec_hash, tl.scan_start + tl.carry(), n,
+        const uint32_t fresh_n = insert_run(a.rec_hash, (tl.scan_start + tl.carry()) >> a.rec_shift, n,
                                             (unsigned long long *)(a.set_slots + a.set_off[tl.unit]), cap, lane);
         if (lane == 0 && fresh_n) atomicAdd(&a.g_distinct[tl.unit], fresh_n);
     }
@@ -484,11 +485,11 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
         }
     }
     if (a.status->bounds && blockIdx.x == 0 && threadIdx.x == 0) a.report->bounds = a.status->bounds;
-    if (a.status->rec_overflow) {
+    if (a.status->rec_overflow || a.status->run_overflow) {
         // sticky: the status words are cleared before the next chunk, the report is read when the batch is waited for
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            a.report->overflow = 1;
-            atomicMax(&a.report->need, (a.status->set_cursor + 3) / 4);
+            atomicOr(&a.report->overflow, (a.status->rec_overflow ? 1u : 0u) | (a.status->run_overflow ? 2u : 0u));
+            if (a.status->rec_overflow) atomicMax(&a.report->need, (a.status->set_cursor + 3) / 4);
         }
         return; // an overflowed attempt is re-run: do not count it
     }

@@ -78,7 +78,8 @@ struct WaveShared {
     uint32_t total[DCN_WAVE];           // per unit slot: emitted minimizers minus those failing the ACGT test
     uint32_t hits[DCN_WAVE];            // per unit slot: distinct hits
     uint32_t items[DCN_WAVE];           // per unit slot: emitted minimizers (bounds the ring span)
-    uint32_t hraw[DCN_WAVE];            // per unit slot: hits pushed through the ring so far
+    uint16_t hraw[DCN_WAVE];            // per unit slot: hits pushed through the ring so far (at most DCN_RCAP - 64)
+    uint32_t ucap[DCN_WAVE];            // per unit slot: first the unit's window span in this wave, then the hits its run holds
     uint32_t unit_of[DCN_WAVE];         // unit slot -> global unit id
     uint16_t start[DCN_WAVE + 2];       // exclusive prefix of the per-lane list lengths
     uint32_t uhits[DCN_WAVE];           // per unit slot: hits written to the unit's run of the record array so far
@@ -165,9 +166,10 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     sh.hraw[lane] = 0;
     sh.lok[lane] = 0;
     sh.uhits[lane] = 0;
+    sh.ucap[lane] = 0;
     if (head) {
         sh.unit_of[uslot] = t.unit;
-        sh.run_base[uslot] = t.scan_start + carry;
+        sh.run_base[uslot] = (t.scan_start + carry) >> a.rec_shift;
         bool loc = false;
         if (!DUMP) {
             if (t.whole_unit()) { // the unit's only tile is this lane's
@@ -191,6 +193,21 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
         sh.tab[lane] = e;
     }
     __syncthreads();
+    if (!DUMP) {
+        // A unit's run of the record array starts at the slot of its first window in this wave and may grow up to the slot of
+        // its last: with one slot per 2^rec_shift windows it holds that many times fewer hits than the unit has windows
+        // here, which real sequence never fills (one minimizer per ~8 windows) -- a run that would is refused and the
+        // batch comes back with one slot per window (api.hip).
+        // (a read's last tile -- the only kind that can be a few windows short of a slot -- also owns the l-1 positions
+        // behind its last window, where no window of this read or of the next one starts)
+        const uint32_t head_lane = 63u - (uint32_t)__clzll(head_mask & ((2ull << lane) - 1));
+        const uint64_t first_win = (uint64_t)__shfl((long long)(t.scan_start + carry), head_lane, 64);
+        const uint32_t slack = t.n_windows() < a.tile_windows ? l - 1 : 0u;
+        if (have_tile && t.n_windows()) atomicMax(&sh.ucap[uslot], (uint32_t)(t.scan_start + carry + t.n_windows() + slack - first_win));
+        __syncthreads();
+        if (head) sh.ucap[uslot] = (uint32_t)(((first_win + sh.ucap[uslot]) >> a.rec_shift) - (first_win >> a.rec_shift));
+        __syncthreads();
+    }
 
     const uint32_t *packed = a.packed;
     const int64_t s = (int64_t)t.scan_start;
@@ -528,8 +545,12 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                         const uint32_t rank = (uint32_t)__popcll(below) - (uint32_t)__popcll(rb & ((1ull << head_lane) - 1));
                         any_rec = true;
                         if (rec) {
-                            const uint32_t before = sh.uhits[o_uslot[u]];
-                            if (!(DCN_EXP & 512)) a.rec_hash[sh.run_base[o_uslot[u]] + before + rank] = hash[u];
+                            const uint32_t at = sh.uhits[o_uslot[u]] + rank;
+                            if (at < sh.ucap[o_uslot[u]]) {
+                                if (!(DCN_EXP & 512)) a.rec_hash[sh.run_base[o_uslot[u]] + at] = hash[u];
+                            } else {
+                                a.status->run_overflow = 1; // (only with rec_shift > 0; the batch is run again)
+                            }
                             if (hash[u] == 0) a.g_zero[sh.unit_of[o_uslot[u]]] = 1;
                         }
                         if (run_head) { // after every lane of the run has read the old length: one update per run

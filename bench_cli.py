@@ -107,10 +107,15 @@ def parse_timing(stderr):
         out["run_wall_s"] = float(m.group(1))
         out["busy_core_s"] = {"parse": float(m.group(2)), "gpu_stage": float(m.group(3)), "format": float(m.group(5)),
                               "write": float(m.group(6))}
-    m = re.search(r"index loaded ([0-9.]+), all input parsed\+queued ([0-9.]+), GPU stage drained ([0-9.]+), all written ([0-9.]+)", stderr)
+    m = re.search(r"timing: process CPU ([0-9.]+) s user \+ ([0-9.]+) s system", stderr)
     if m:
-        out["milestones_s"] = {"index_loaded": float(m.group(1)), "input_parsed_and_queued": float(m.group(2)),
-                               "gpu_stage_drained": float(m.group(3)), "all_written": float(m.group(4))}
+        out["process_cpu_s"] = {"user": float(m.group(1)), "system": float(m.group(2))}
+    m = re.search(r"index loaded ([0-9.]+), contexts ready ([0-9.]+), all input parsed\+queued ([0-9.]+), GPU stage drained ([0-9.]+), "
+                  r"all written ([0-9.]+)", stderr)
+    if m:
+        out["milestones_s"] = {"index_loaded": float(m.group(1)), "contexts_ready": float(m.group(2)),
+                               "input_parsed_and_queued": float(m.group(3)), "gpu_stage_drained": float(m.group(4)),
+                               "all_written": float(m.group(5))}
     return out
 
 

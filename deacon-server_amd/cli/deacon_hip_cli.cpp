@@ -18,6 +18,7 @@
 // Input/output compression: gzip via zlib; zstd and xz through the installed runtime libraries (codecs.hpp).
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
 #include <sys/vfs.h>
@@ -407,6 +408,12 @@ struct Batch {
     std::vector<struct iovec> iov1;  // plain single-file output: what to write, in order -- ranges of the mapped input
                                      // (records that already have their output form) and pieces of out1
     std::vector<uint8_t, DefaultInitAllocator<uint8_t>> bases;  // concatenated sequences (what dcn_filter_batch takes)
+    // ... or, from the chunk parsers, the same stream already in the form dcn_filter_batch_packed takes (2 bits per base
+    // + 1 invalid bit per base, whole 32-base groups): every Rec::seq_off then points at the record's one sequence line
+    // in chars() instead of into `bases`
+    std::vector<uint32_t, DefaultInitAllocator<uint32_t>> packed, invmask;
+    bool seq_in_chars = false;
+    const char *seq_ptr(const Rec &r) const;
     std::vector<uint64_t> offsets{0};
     std::vector<uint32_t> unit_id;
     std::vector<Rec> recs;
@@ -417,6 +424,7 @@ struct Batch {
     std::vector<uint64_t> gpu_seqs;
     std::vector<std::vector<uint64_t>> sub_off;
     std::vector<std::vector<uint32_t>> sub_uid;
+    std::vector<std::vector<uint32_t>> sub_packed, sub_mask;  // (packed batches: the later pieces' bits, moved to base 0)
     uint64_t out_off = 0, out_bytes = 0;  // mapped output: where this batch's kept records go, and how many bytes
     uint64_t out_off2 = 0, out_bytes2 = 0;  // ... and the second mates', when they have a mapped file of their own (-O)
     size_t raw_end = 0;     // chunk reader: `text` holds raw input, whole records in [0, raw_end) ...
@@ -425,6 +433,9 @@ struct Batch {
     void clear() {
         text.clear();
         bases.clear();
+        packed.clear();
+        invmask.clear();
+        seq_in_chars = false;
         offsets.assign(1, 0);
         unit_id.clear();
         recs.clear();
@@ -445,6 +456,8 @@ struct Batch {
         gpu_seqs.clear();
         sub_off.clear();
         sub_uid.clear();
+        sub_packed.clear();
+        sub_mask.clear();
         out_off = out_bytes = 0;
         out_off2 = out_bytes2 = 0;
         raw_end = 0;
@@ -452,6 +465,10 @@ struct Batch {
         paired = false;
     }
 };
+
+inline const char *Batch::seq_ptr(const Rec &r) const {
+    return seq_in_chars ? chars() + r.seq_off : reinterpret_cast<const char *>(bases.data()) + r.seq_off;
+}
 
 // Batches travel reader -> parsers -> GPU stage -> formatters -> writer and come back here: their vectors (12 MB of
 // bases, 5 MB of records per chunk) are reused instead of being mapped, page-faulted and unmapped once per chunk
@@ -831,11 +848,95 @@ __attribute__((target("avx2"))) inline size_t line_end_avx2(const char *d, size_
 }
 #endif
 
-// One record of a mapped file: the record starting at d[p] (p < b, not a blank line) -> its Rec, its sequence appended
-// at bases + nb (COPY; a counting pass leaves the bases alone), the position behind it returned.  `shift` is added to
-// the offsets the Rec keeps into the mapping (two mapped files share one base pointer: paired inputs).
-template <bool AVX2, bool COPY>
-inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq, uint8_t *bases, size_t &nb, Rec &r, uint64_t shift) {
+// The batch stream written in the library's packed form while the records are parsed (dcn_filter_batch_packed,
+// include/deacon_hip.h: base i = bits [2(i%32), +2) of the i/32-th 64-bit word, code (c >> 1) & 3; invalid bit i%32 of
+// mask word i/32 set iff the byte is not one of ACGTacgt -- PackedSeqVec::from_ascii and the mask loop of
+// src/filter_common.rs:238-258).  Sequence lines arrive at any base offset: a 64 + 32-bit accumulator takes 32 bases per
+// step and every output word is stored once.  The ASCII never gets a copy of its own: one read of the mapped input,
+// 0.375 bytes written per base (the ASCII form writes 1 and has the library's host threads read it again to pack it).
+struct PackSink {
+    uint32_t *P = nullptr;  // two u32 words per 32-base group, stored as one u64 (little endian)
+    uint32_t *M = nullptr;
+    uint64_t accP = 0;
+    uint32_t accM = 0;
+    unsigned fill = 0;  // bases in the accumulator, 0..31
+    size_t g = 0;       // groups stored so far
+    bool multi = false; // a record whose sequence spans several lines was met (its formatter needs contiguous bases)
+
+    inline void put(uint64_t v, uint32_t m, unsigned n) {  // n <= 32 bases, bits above them zero
+        accP |= v << (2 * fill);
+        accM |= m << fill;
+        if (fill + n >= 32) {
+            std::memcpy(P + 2 * g, &accP, 8);
+            M[g] = accM;
+            ++g;
+            accP = fill ? v >> (2 * (32 - fill)) : 0;
+            accM = fill ? m >> (32 - fill) : 0;
+            fill = fill + n - 32;
+        } else {
+            fill += n;
+        }
+    }
+#if defined(__x86_64__)
+    // n bytes at s; bytes up to `limit` may be read (the chunk's end: whatever follows a line there is input as well)
+    __attribute__((target("avx2,bmi2"))) void push(const char *s, size_t n, const char *limit) {
+        const __m256i lower = _mm256_set1_epi8(0x20);
+        const __m256i ca = _mm256_set1_epi8('a'), cc = _mm256_set1_epi8('c'), cg = _mm256_set1_epi8('g'), ct = _mm256_set1_epi8('t');
+        const uint64_t sel = 0x0606060606060606ull;  // bits 1..2 of every byte = (c >> 1) & 3
+        for (size_t i = 0; i < n; i += 32) {
+            const unsigned m = n - i < 32 ? (unsigned)(n - i) : 32u;
+            __m256i v;
+            if (s + i + 32 <= limit) {
+                v = _mm256_loadu_si256((const __m256i *)(s + i));
+            } else {
+                char buf[32] = {0};
+                std::memcpy(buf, s + i, m);
+                v = _mm256_loadu_si256((const __m256i *)buf);
+            }
+            uint64_t code = _pext_u64((uint64_t)_mm256_extract_epi64(v, 0), sel) | (_pext_u64((uint64_t)_mm256_extract_epi64(v, 1), sel) << 16) |
+                            (_pext_u64((uint64_t)_mm256_extract_epi64(v, 2), sel) << 32) | (_pext_u64((uint64_t)_mm256_extract_epi64(v, 3), sel) << 48);
+            const __m256i l = _mm256_or_si256(v, lower);
+            const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(l, ca), _mm256_cmpeq_epi8(l, cc)),
+                                               _mm256_or_si256(_mm256_cmpeq_epi8(l, cg), _mm256_cmpeq_epi8(l, ct)));
+            uint32_t inv = ~(uint32_t)_mm256_movemask_epi8(ok);
+            if (m < 32) {
+                code &= (1ull << (2 * m)) - 1;
+                inv &= (1u << m) - 1;
+            }
+            put(code, inv, m);
+        }
+    }
+#else
+    void push(const char *, size_t, const char *) {}
+#endif
+    size_t finish() {  // stores the last, partial group (bits behind the stream's end stay zero: 'A', valid); groups written
+        if (fill) {
+            std::memcpy(P + 2 * g, &accP, 8);
+            M[g] = accM;
+            ++g;
+            accP = 0, accM = 0, fill = 0;
+        }
+        return g;
+    }
+};
+
+inline bool cli_can_pack() {  // the packing parser needs AVX2 + BMI2 (pext); other hosts parse to ASCII
+#if defined(__x86_64__)
+    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !std::getenv("DCN_CLI_NO_AVX2") &&
+                           !std::getenv("DCN_CLI_NO_PACKED_PARSE");
+    return ok;
+#else
+    return false;
+#endif
+}
+
+// One record of a mapped file: the record starting at d[p] (p < b, not a blank line) -> its Rec, the position behind it
+// returned.  MODE 1: its sequence appended at bases + nb; MODE 2: packed into *ps, Rec::seq_off = the sequence line in the
+// mapping; MODE 0: a counting pass, the sequence is not touched.  `shift` is added to the offsets the Rec keeps into the
+// mapping (two mapped files share one base pointer: paired inputs).
+template <bool AVX2, int MODE>
+inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq, uint8_t *bases, size_t &nb, Rec &r, uint64_t shift,
+                                  PackSink *ps = nullptr) {
     auto eol = [&](size_t q) {
 #if defined(__x86_64__)
         if (AVX2) return line_end_avx2(d, b, q);
@@ -847,6 +948,7 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
     if (d[p] != (fastq ? '@' : '>')) die("Invalid FASTX record start: expected '>' or '@'");
     r.id_off = shift + p + 1;
     r.id_len = (uint32_t)(trim(p + 1, e0) - (p + 1));
+    const size_t nb0 = nb;
     r.seq_off = nb;
     r.rec_off = 0;
     r.rec_len = 0;
@@ -858,7 +960,8 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
         if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
         size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
         if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
-        if (COPY) std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
+        if (MODE == 1) std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
+        if (MODE == 2) ps->push(d + s1, t1 - s1, d + b), r.seq_off = shift + s1;
         nb += t1 - s1;
         r.qual_off = shift + s3;
         if (t1 == e1 && t3 == e3 && e2 == s2 + 1 && e3 < b && r.id_len == e0 - (p + 1) && e3 + 1 - p < (1ull << 32)) {
@@ -869,10 +972,12 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
     } else {
         size_t q = e0 + 1, lines = 0, last_e = 0;
         bool cr = false;
+        const size_t first_line = q;
         while (q < b && d[q] != '>') {
             size_t e = eol(q);
             cr = cr || trim(q, e) != e;
-            if (COPY) std::memcpy(bases + nb, d + q, trim(q, e) - q);
+            if (MODE == 1) std::memcpy(bases + nb, d + q, trim(q, e) - q);
+            if (MODE == 2) ps->push(d + q, trim(q, e) - q, d + b);
             nb += trim(q, e) - q;
             q = e + 1;
             last_e = e;
@@ -883,9 +988,13 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
             r.rec_off = shift + p;
             r.rec_len = (uint32_t)(last_e + 1 - p);
         }
+        if (MODE == 2) {
+            if (lines > 1) ps->multi = true;
+            r.seq_off = shift + first_line;
+        }
         p = q;
     }
-    r.seq_len = (uint32_t)(nb - r.seq_off);
+    r.seq_len = (uint32_t)(nb - nb0);
     return p;
 }
 
@@ -898,14 +1007,27 @@ inline bool cli_avx2() {
 #endif
 }
 
-// parse the records in [a, b) of the mapped file into batch (ids / qualities stay in the mapping)
-template <bool AVX2>
-void parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
+// parse the records in [a, b) of the mapped file into batch (ids / qualities stay in the mapping).  PACKED: the batch's
+// stream is written 2-bit packed and the sequences stay in the mapping too; false = a record with several sequence lines
+// was met (the formatters want a record's bases in one piece): the caller parses the chunk again in the ASCII form
+template <bool AVX2, bool PACKED>
+bool parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
     out.ext = d;
     // the sequences of a chunk are at most its own size: one allocation, written through a raw pointer (insert() /
     // push_back() per record cost more than the copy itself)
-    out.bases.resize((b - a) / (fastq ? 2 : 1) + 64);
-    uint8_t *bases = out.bases.data();
+    const size_t max_bases = (b - a) / (fastq ? 2 : 1) + 64;
+    PackSink ps;
+    uint8_t *bases = nullptr;
+    if (PACKED) {
+        out.bases.clear();
+        out.packed.resize(2 * (max_bases / 32 + 2));
+        out.invmask.resize(max_bases / 32 + 2);
+        ps.P = out.packed.data();
+        ps.M = out.invmask.data();
+    } else {
+        out.bases.resize(max_bases);
+        bases = out.bases.data();
+    }
     size_t nb = 0;
     out.recs.reserve((b - a) / 192 + 16);
     out.offsets.reserve((b - a) / 192 + 17);
@@ -916,16 +1038,33 @@ void parse_mapped_chunk_impl(const char *d, size_t a, size_t b, bool fastq, Batc
             continue;
         }
         Rec r;
-        p = parse_mapped_record<AVX2, true>(d, p, b, fastq, bases, nb, r, 0);
+        p = parse_mapped_record<AVX2, PACKED ? 2 : 1>(d, p, b, fastq, bases, nb, r, 0, &ps);
         out.recs.push_back(r);
         out.offsets.push_back(nb);
+        if (PACKED && ps.multi) return false;
     }
-    out.bases.resize(nb);
+    if (PACKED) {
+        size_t groups = ps.finish();
+        if (groups == 0) ps.P[0] = ps.P[1] = 0, ps.M[0] = 0, groups = 1;  // (only empty sequences: the arrays still have to exist)
+        out.packed.resize(2 * groups);
+        out.invmask.resize(groups);
+        out.seq_in_chars = true;
+    } else {
+        out.bases.resize(nb);
+    }
+    return true;
 }
 
-void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out) {
-    if (cli_avx2()) return parse_mapped_chunk_impl<true>(d, a, b, fastq, out);
-    parse_mapped_chunk_impl<false>(d, a, b, fastq, out);
+void parse_mapped_chunk(const char *d, size_t a, size_t b, bool fastq, Batch &out, bool packed = false) {
+    if (packed && cli_can_pack()) {
+        if (parse_mapped_chunk_impl<true, true>(d, a, b, fastq, out)) return;
+        out.recs.clear();
+        out.offsets.assign(1, 0);
+        out.packed.clear();
+        out.invmask.clear();
+    }
+    if (cli_avx2()) parse_mapped_chunk_impl<true, false>(d, a, b, fastq, out);
+    else parse_mapped_chunk_impl<false, false>(d, a, b, fastq, out);
 }
 
 // ---- two mapped files, mates in step (the parallel form of the paired reader) ------------------------------------------
@@ -938,8 +1077,8 @@ size_t count_mapped_records(const char *d, size_t a, size_t b, bool fastq) {
             ++p;
             continue;
         }
-        p = cli_avx2() ? parse_mapped_record<true, false>(d, p, b, fastq, nullptr, nb, r, 0)
-                       : parse_mapped_record<false, false>(d, p, b, fastq, nullptr, nb, r, 0);
+        p = cli_avx2() ? parse_mapped_record<true, 0>(d, p, b, fastq, nullptr, nb, r, 0)
+                       : parse_mapped_record<false, 0>(d, p, b, fastq, nullptr, nb, r, 0);
         ++n;
     }
     return n;
@@ -954,8 +1093,8 @@ size_t skip_mapped_records(const char *d, size_t a, size_t size, bool fastq, siz
             ++p;
             continue;
         }
-        p = cli_avx2() ? parse_mapped_record<true, false>(d, p, size, fastq, nullptr, nb, r, 0)
-                       : parse_mapped_record<false, false>(d, p, size, fastq, nullptr, nb, r, 0);
+        p = cli_avx2() ? parse_mapped_record<true, 0>(d, p, size, fastq, nullptr, nb, r, 0)
+                       : parse_mapped_record<false, 0>(d, p, size, fastq, nullptr, nb, r, 0);
         --skip;
     }
     return p;
@@ -963,14 +1102,25 @@ size_t skip_mapped_records(const char *d, size_t a, size_t size, bool fastq, siz
 
 // mates of [a1, b1) in file 1 and of [a2, b2) in file 2 (the same number of records), interleaved into one batch
 // (mate 1, mate 2, ...).  Offsets into the mappings are relative to the lower of the two base pointers.
-template <bool AVX2>
-void parse_mapped_pairs_impl(const char *d1, size_t a1, size_t b1, const char *d2, size_t a2, size_t b2, bool fastq, Batch &out) {
+template <bool AVX2, bool PACKED>
+bool parse_mapped_pairs_impl(const char *d1, size_t a1, size_t b1, const char *d2, size_t a2, size_t b2, bool fastq, Batch &out) {
     const char *base = d1 < d2 ? d1 : d2;
     const uint64_t sh1 = (uint64_t)(d1 - base), sh2 = (uint64_t)(d2 - base);
     out.ext = base;
     out.paired = true;
-    out.bases.resize(((b1 - a1) + (b2 - a2)) / (fastq ? 2 : 1) + 128);  // a sequence is at most (half of) its record's bytes
-    uint8_t *bases = out.bases.data();
+    const size_t max_bases = ((b1 - a1) + (b2 - a2)) / (fastq ? 2 : 1) + 128;  // a sequence is at most (half of) its record's bytes
+    PackSink ps;
+    uint8_t *bases = nullptr;
+    if (PACKED) {
+        out.bases.clear();
+        out.packed.resize(2 * (max_bases / 32 + 2));
+        out.invmask.resize(max_bases / 32 + 2);
+        ps.P = out.packed.data();
+        ps.M = out.invmask.data();
+    } else {
+        out.bases.resize(max_bases);
+        bases = out.bases.data();
+    }
     size_t nb = 0;
     out.recs.reserve((b1 - a1) / 96 + 32);
     out.offsets.reserve((b1 - a1) / 96 + 33);
@@ -982,23 +1132,41 @@ void parse_mapped_pairs_impl(const char *d1, size_t a1, size_t b1, const char *d
         while (p2 < b2 && d2[p2] == '\n') ++p2;
         if (p1 >= b1 || p2 >= b2) break;
         Rec r;
-        p1 = parse_mapped_record<AVX2, true>(d1, p1, b1, fastq, bases, nb, r, sh1);
+        p1 = parse_mapped_record<AVX2, PACKED ? 2 : 1>(d1, p1, b1, fastq, bases, nb, r, sh1, &ps);
         out.recs.push_back(r);
         out.offsets.push_back(nb);
-        p2 = parse_mapped_record<AVX2, true>(d2, p2, b2, fastq, bases, nb, r, sh2);
+        p2 = parse_mapped_record<AVX2, PACKED ? 2 : 1>(d2, p2, b2, fastq, bases, nb, r, sh2, &ps);
         out.recs.push_back(r);
         out.offsets.push_back(nb);
         out.unit_id.push_back(unit);
         out.unit_id.push_back(unit);
         ++unit;
+        if (PACKED && ps.multi) return false;
     }
     if (p1 < b1 || p2 < b2) die("internal: the two inputs' chunks do not hold the same number of records");
-    out.bases.resize(nb);
+    if (PACKED) {
+        size_t groups = ps.finish();
+        if (groups == 0) ps.P[0] = ps.P[1] = 0, ps.M[0] = 0, groups = 1;  // (only empty sequences: the arrays still have to exist)
+        out.packed.resize(2 * groups);
+        out.invmask.resize(groups);
+        out.seq_in_chars = true;
+    } else {
+        out.bases.resize(nb);
+    }
+    return true;
 }
 
-void parse_mapped_pairs(const char *d1, size_t a1, size_t b1, const char *d2, size_t a2, size_t b2, bool fastq, Batch &out) {
-    if (cli_avx2()) return parse_mapped_pairs_impl<true>(d1, a1, b1, d2, a2, b2, fastq, out);
-    parse_mapped_pairs_impl<false>(d1, a1, b1, d2, a2, b2, fastq, out);
+void parse_mapped_pairs(const char *d1, size_t a1, size_t b1, const char *d2, size_t a2, size_t b2, bool fastq, Batch &out, bool packed = false) {
+    if (packed && cli_can_pack()) {
+        if (parse_mapped_pairs_impl<true, true>(d1, a1, b1, d2, a2, b2, fastq, out)) return;
+        out.recs.clear();
+        out.offsets.assign(1, 0);
+        out.unit_id.clear();
+        out.packed.clear();
+        out.invmask.clear();
+    }
+    if (cli_avx2()) parse_mapped_pairs_impl<true, false>(d1, a1, b1, d2, a2, b2, fastq, out);
+    else parse_mapped_pairs_impl<false, false>(d1, a1, b1, d2, a2, b2, fastq, out);
 }
 
 // fn(i) for i in [0, n) on `threads` threads
@@ -1050,7 +1218,7 @@ BatchStats format_batch(Batch &b, bool rename, bool split_mates, uint64_t rename
             dst.insert(dst.end(), chars + r.id_off, chars + r.id_off + r.id_len);
         }
         dst.push_back('\n');
-        dst.insert(dst.end(), b.bases.begin() + r.seq_off, b.bases.begin() + r.seq_off + r.seq_len);
+        dst.insert(dst.end(), b.seq_ptr(r), b.seq_ptr(r) + r.seq_len);
         if (fasta) {
             dst.push_back('\n');
         } else {
@@ -1125,7 +1293,7 @@ BatchStats format_batch_mapped(const Batch &b, bool rename, uint64_t rename_base
         if (rename) o += std::snprintf(o, 24, "%llu", (unsigned long long)counter);  // the '\0' is overwritten below
         else std::memcpy(o, chars + r.id_off, r.id_len), o += r.id_len;
         *o++ = '\n';
-        std::memcpy(o, b.bases.data() + r.seq_off, r.seq_len), o += r.seq_len;
+        std::memcpy(o, b.seq_ptr(r), r.seq_len), o += r.seq_len;
         if (fasta) {
             *o++ = '\n';
         } else {
@@ -1187,7 +1355,7 @@ BatchStats format_batch_gather(Batch &b, bool rename, uint64_t rename_base) {
             b.out1.insert(b.out1.end(), chars + r.id_off, chars + r.id_off + r.id_len);
         }
         b.out1.push_back('\n');
-        b.out1.insert(b.out1.end(), b.bases.begin() + r.seq_off, b.bases.begin() + r.seq_off + r.seq_len);
+        b.out1.insert(b.out1.end(), b.seq_ptr(r), b.seq_ptr(r) + r.seq_len);
         if (fasta) {
             b.out1.push_back('\n');
         } else {
@@ -1381,7 +1549,7 @@ struct StageClock {
 // ---- deacon filter (src/local_filter.rs:575-824) ---------------------------------------------------------------
 int run_filter(const FilterArgs &a) {
     StageClock t_parse, t_gpu, t_gpu_wait, t_format, t_write, t_push_wait;
-    double m_index = 0, m_feeder_done = 0, m_gpu_done = 0, m_written = 0;  // milestones, seconds since start
+    double m_index = 0, m_ctx = 0, m_feeder_done = 0, m_gpu_done = 0, m_written = 0;  // milestones, seconds since start
     const bool cli_timing = std::getenv("DCN_CLI_TIMING") != nullptr;
     using clock = std::chrono::steady_clock;
     auto start = clock::now();
@@ -1467,6 +1635,9 @@ int run_filter(const FilterArgs &a) {
     // one stream that is not a mappable plain file (stdin, gzip / zstd / xz): the chunk reader below
     const bool chunk_in = !paired && !parallel_in && !std::getenv("DCN_CLI_NO_CHUNK_READER");
     const bool pool_in = parallel_in || chunk_in || pair_in;  // batches come out of the parser pool
+    // the chunk parsers write the batch stream 2-bit packed (no ASCII copy of the bases, no second pass of the library's
+    // host threads over it); --debug prints k-mer strings and wants the ASCII
+    const bool packed_parse = pool_in && cli_can_pack() && !a.debug;
     BatchPool pool;
     Queue<std::unique_ptr<Batch>> parsed(4);
     std::unique_ptr<OrderedStage> parse_stage;
@@ -1475,11 +1646,11 @@ int run_filter(const FilterArgs &a) {
         const char *d = mapped.data;
         size_t size = mapped.size;
         // (enough chunks in flight, ~12 MB each, to keep the parsers busy while the GPU runtime starts and the index loads)
-        parse_stage.reset(new OrderedStage(n_workers, 4 * n_workers + 8, [d, fastq_in, &t_parse](Batch &b) {
+        parse_stage.reset(new OrderedStage(n_workers, 4 * n_workers + 8, [d, fastq_in, packed_parse, &t_parse](Batch &b) {
             StageClock::Scope sc(t_parse);
             size_t ca = (size_t)b.offsets[0], cb = (size_t)b.seq_no;  // chunk bounds travel in the empty batch
             b.offsets.assign(1, 0);
-            parse_mapped_chunk(d, ca, cb, fastq_in, b);
+            parse_mapped_chunk(d, ca, cb, fastq_in, b, packed_parse);
         }));
         reader = std::thread([&, d, size] {
             // chunks stay well under glibc's 32 MB mmap threshold: the per-batch vectors are then recycled by malloc
@@ -1503,13 +1674,13 @@ int run_filter(const FilterArgs &a) {
         const char *d1 = mapped.data, *d2 = mapped2.data;
         const size_t size1 = mapped.size, size2 = mapped2.size;
         const bool fq = d1[0] == '@';
-        parse_stage.reset(new OrderedStage(n_workers, 4 * n_workers + 8, [d1, d2, fq, &t_parse](Batch &b) {
+        parse_stage.reset(new OrderedStage(n_workers, 4 * n_workers + 8, [d1, d2, fq, packed_parse, &t_parse](Batch &b) {
             StageClock::Scope sc(t_parse);
             // chunk bounds travel in the empty batch: file 1 in offsets[0] / seq_no, file 2 in out_off / out_bytes
             const size_t a1 = (size_t)b.offsets[0], b1 = (size_t)b.seq_no, a2 = (size_t)b.out_off, b2 = (size_t)b.out_bytes;
             b.offsets.assign(1, 0);
             b.out_off = b.out_bytes = 0;
-            parse_mapped_pairs(d1, a1, b1, d2, a2, b2, fq, b);
+            parse_mapped_pairs(d1, a1, b1, d2, a2, b2, fq, b, packed_parse);
         }));
         reader = std::thread([&, d1, d2, size1, size2, fq] {
             // Mates sit at the same record NUMBER of their files, not at the same byte: both files are cut into chunks at
@@ -1555,10 +1726,10 @@ int run_filter(const FilterArgs &a) {
         // stdin or a compressed file, one stream: this thread only decompresses and cuts the stream into chunks of whole
         // records (each batch keeps its raw chunk: ids and qualities stay in it); the worker pool parses them with the
         // parser of the mapped path.  (One thread doing both ran at the parser's pace: ~1 GB/s against zstd's 1.5+.)
-        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 4, [&t_parse](Batch &b) {
+        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 4, [packed_parse, &t_parse](Batch &b) {
             StageClock::Scope sc(t_parse);
             b.offsets.assign(1, 0);
-            parse_mapped_chunk(b.text.data(), 0, b.raw_end, b.raw_fastq, b);
+            parse_mapped_chunk(b.text.data(), 0, b.raw_end, b.raw_fastq, b, packed_parse);
         }));
         reader = std::thread([&] {
             Input in(a.input);
@@ -1707,6 +1878,7 @@ int run_filter(const FilterArgs &a) {
     } catch (const std::exception &e) {
         die(e.what());
     }
+    m_ctx = std::chrono::duration<double>(clock::now() - start).count();
     Queue<std::unique_ptr<Batch>> submitted(2 * a.devices.size() + 2);
     auto submit_batch = [&](Batch &b) {
         b.gpu_seqs.clear();
@@ -1730,7 +1902,37 @@ int run_filter(const FilterArgs &a) {
             if (r1 == r0) die("a single record is longer than the largest batch (" + std::to_string(cfg.max_batch_bases) + " bases)");
             const size_t u0 = r0 / per;
             deacon::MultiGpuFilter::Job job;
-            job.bases = b.bases.data() + b.offsets[r0];
+            if (b.seq_in_chars) {
+                job.packed = b.packed.data();
+                job.invmask = b.invmask.data();
+                if (r0 != 0) {  // a later piece: its bits moved so that its first base is base 0 of a stream of its own
+                    const uint64_t base0 = b.offsets[r0], nbp = b.offsets[r1] - base0, groups = (nbp + 31) / 32;
+                    const uint64_t alloc = std::max<uint64_t>(groups, 1);
+                    const uint64_t g0 = base0 / 32, have = b.invmask.size();
+                    const unsigned sh = (unsigned)(base0 % 32);
+                    b.sub_packed.emplace_back(2 * alloc, 0u);
+                    b.sub_mask.emplace_back(alloc, 0u);
+                    uint32_t *sp = b.sub_packed.back().data(), *sm = b.sub_mask.back().data();
+                    auto P = [&](uint64_t g) {
+                        uint64_t v = 0;
+                        if (g < have) std::memcpy(&v, b.packed.data() + 2 * g, 8);
+                        return v;
+                    };
+                    auto M = [&](uint64_t g) { return g < have ? b.invmask[g] : 0u; };
+                    for (uint64_t j = 0; j < groups; ++j) {
+                        uint64_t v = sh ? (P(g0 + j) >> (2 * sh)) | (P(g0 + j + 1) << (64 - 2 * sh)) : P(g0 + j);
+                        uint32_t m = sh ? (M(g0 + j) >> sh) | (M(g0 + j + 1) << (32 - sh)) : M(g0 + j);
+                        const uint64_t left = nbp - 32 * j;  // bases of this group that belong to the piece
+                        if (left < 32) v &= (1ull << (2 * left)) - 1, m &= (1u << left) - 1;
+                        std::memcpy(sp + 2 * j, &v, 8);
+                        sm[j] = m;
+                    }
+                    job.packed = sp;
+                    job.invmask = sm;
+                }
+            } else {
+                job.bases = b.bases.data() + b.offsets[r0];
+            }
             job.offsets = b.offsets.data();
             job.unit_id = b.paired ? b.unit_id.data() : nullptr;
             if (r0 != 0) {  // offsets and unit ids of a later piece start from zero again
@@ -1817,12 +2019,18 @@ int run_filter(const FilterArgs &a) {
              output_bp = tot.output_bp, filtered_bp = tot.filtered_bp;
 
     double secs = std::chrono::duration<double>(clock::now() - start).count();
+    if (cli_timing) {
+        struct rusage ru;
+        if (getrusage(RUSAGE_SELF, &ru) == 0)  // every thread of the process, the library's host threads and the runtime's included
+            std::fprintf(stderr, "timing: process CPU %.3f s user + %.3f s system\n", ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6,
+                         ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6);
+    }
     if (cli_timing)
         std::fprintf(stderr, "timing: wall %.3f s; busy seconds: parse %.3f (all workers), GPU stage %.3f (main thread waited %.3f for it), "
                              "format %.3f (all workers), write %.3f; main thread blocked pushing to format %.3f\n"
-                             "timing: milestones (s): index loaded %.3f, all input parsed+queued %.3f, "
+                             "timing: milestones (s): index loaded %.3f, contexts ready %.3f, all input parsed+queued %.3f, "
                              "GPU stage drained %.3f, all written %.3f\n", secs, t_parse.seconds(), t_gpu.seconds(),
-                     t_gpu_wait.seconds(), t_format.seconds(), t_write.seconds(), t_push_wait.seconds(), m_index,
+                     t_gpu_wait.seconds(), t_format.seconds(), t_write.seconds(), t_push_wait.seconds(), m_index, m_ctx,
                      m_feeder_done, m_gpu_done, m_written);
     uint64_t seqs_out = total_seqs - filtered_seqs;
     auto prop = [](uint64_t x, uint64_t y) { return y ? (double)x / (double)y : 0.0; };
@@ -2064,18 +2272,51 @@ int main(int argc, char **argv) {
         }
         if (args[0] == "bench-parse" && args.size() >= 2) {  // hidden: the parser pool alone on a plain FASTX file (no GPU)
             size_t threads = 8;
-            for (size_t i = 2; i + 1 < args.size(); ++i)
-                if (args[i] == "-t") threads = (size_t)std::atoll(args[i + 1].c_str());
+            bool packed = cli_can_pack(), verify = false;
+            for (size_t i = 2; i < args.size(); ++i) {
+                if (args[i] == "-t" && i + 1 < args.size()) threads = (size_t)std::atoll(args[++i].c_str());
+                else if (args[i] == "--ascii") packed = false;
+                else if (args[i] == "--verify") verify = true;  // both forms of every chunk, compared (dcn_pack_ascii as the judge)
+            }
             MappedFile mf;
             if (!mf.open(args[1])) die("cannot map " + args[1]);
             const bool fq = mf.data[0] == '@';
             auto t0 = std::chrono::steady_clock::now();
             std::vector<std::pair<size_t, size_t>> chunks;
-            const size_t chunk = std::min<size_t>(std::max<size_t>(mf.size / (4 * threads), 4u << 20), 24u << 20);
+            size_t chunk = std::min<size_t>(std::max<size_t>(mf.size / (4 * threads), 4u << 20), 24u << 20);
+            if (const char *e = std::getenv("DCN_CLI_CHUNK_KB")) chunk = (size_t)std::max(1, std::atoi(e)) << 10;  // test hook
             for (size_t pos = 0; pos < mf.size;) {
                 size_t end = pos + chunk >= mf.size ? mf.size : next_record_start(mf.data, mf.size, pos + chunk, fq);
                 chunks.emplace_back(pos, end);
                 pos = end;
+            }
+            if (verify) {
+                if (!cli_can_pack()) die("bench-parse --verify: this host cannot run the packing parser");
+                size_t n_packed = 0, n_recs = 0;
+                for (auto &c : chunks) {
+                    Batch pa, as;
+                    parse_mapped_chunk(mf.data, c.first, c.second, fq, pa, true);
+                    parse_mapped_chunk(mf.data, c.first, c.second, fq, as, false);
+                    if (pa.recs.size() != as.recs.size() || pa.offsets != as.offsets) die("verify: records / offsets differ");
+                    for (size_t i = 0; i < pa.recs.size(); ++i) {
+                        const Rec &x = pa.recs[i], &y = as.recs[i];
+                        if (x.id_off != y.id_off || x.id_len != y.id_len || x.seq_len != y.seq_len || x.qual_off != y.qual_off ||
+                            x.rec_off != y.rec_off || x.rec_len != y.rec_len || std::memcmp(pa.seq_ptr(x), as.seq_ptr(y), x.seq_len) != 0)
+                            die("verify: record " + std::to_string(i) + " differs");
+                    }
+                    n_recs += pa.recs.size();
+                    if (!pa.seq_in_chars) continue;  // (a multi-line record: the chunk fell back to ASCII)
+                    ++n_packed;
+                    const uint64_t nb = as.bases.size(), groups = std::max<uint64_t>((nb + 31) / 32, 1);
+                    std::vector<uint32_t> rp(2 * groups, 0), rm(groups, 0);
+                    uint32_t nl = 0;
+                    deacon::check(dcn_pack_ascii(as.bases.data(), nb, rp.data(), rm.data(), &nl));
+                    if (pa.packed.size() != rp.size() || pa.invmask.size() != rm.size() ||
+                        std::memcmp(pa.packed.data(), rp.data(), 4 * rp.size()) != 0 || std::memcmp(pa.invmask.data(), rm.data(), 4 * rm.size()) != 0)
+                        die("verify: packed stream differs from dcn_pack_ascii of the ASCII form");
+                }
+                std::printf("verified %zu records in %zu chunks (%zu packed)\n", n_recs, chunks.size(), n_packed);
+                return 0;
             }
             std::atomic<size_t> next{0}, recs{0}, bases{0};
             std::vector<std::thread> pool;
@@ -2084,15 +2325,15 @@ int main(int argc, char **argv) {
                     Batch b;  // recycled, as the pipeline's pool does
                     for (size_t i; (i = next.fetch_add(1)) < chunks.size();) {
                         b.clear();
-                        parse_mapped_chunk(mf.data, chunks[i].first, chunks[i].second, fq, b);
+                        parse_mapped_chunk(mf.data, chunks[i].first, chunks[i].second, fq, b, packed);
                         recs += b.recs.size();
-                        bases += b.bases.size();
+                        bases += b.offsets.back();
                     }
                 });
             for (auto &t : pool) t.join();
             double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            std::printf("parsed %zu records, %zu bases, %.2f GB in %.3f s with %zu threads: %.2f GB/s, %.2f Gbp/s\n", recs.load(),
-                        bases.load(), mf.size / 1e9, s, threads, mf.size / s / 1e9, bases.load() / s / 1e9);
+            std::printf("parsed %zu records, %zu bases, %.2f GB in %.3f s with %zu threads (%s): %.2f GB/s, %.2f Gbp/s\n", recs.load(),
+                        bases.load(), mf.size / 1e9, s, threads, packed ? "packed" : "ascii", mf.size / s / 1e9, bases.load() / s / 1e9);
             return 0;
         }
         if (args[0] == "index" && args.size() >= 2 && args[1] == "build") {

@@ -264,6 +264,8 @@ class MultiGpuFilter {
   public:
     struct Job {  // one batch: the arguments of dcn_filter_batch; every array must stay valid until wait(seq) returns
         const uint8_t *bases = nullptr;
+        // ... or, instead of `bases`, the stream as dcn_filter_batch_packed takes it (both set, `bases` null)
+        const uint32_t *packed = nullptr, *invmask = nullptr;
         const uint64_t *offsets = nullptr;
         const uint32_t *unit_id = nullptr;
         uint32_t n_reads = 0;
@@ -390,9 +392,11 @@ class MultiGpuFilter {
             }
             if (have) {
                 uint64_t ticket = 0;
-                int rc = dcn_filter_batch_submit(w.ctx, job.second.bases, job.second.offsets, job.second.unit_id,
-                                                 job.second.n_reads, &p, job.second.keep, job.second.hits,
-                                                 job.second.total, &ticket);
+                const Job &j = job.second;
+                int rc = j.packed ? dcn_filter_batch_packed_submit(w.ctx, j.packed, j.invmask, j.offsets, j.unit_id, j.n_reads, &p,
+                                                                   j.keep, j.hits, j.total, &ticket)
+                                  : dcn_filter_batch_submit(w.ctx, j.bases, j.offsets, j.unit_id, j.n_reads, &p, j.keep, j.hits,
+                                                            j.total, &ticket);
                 if (rc != DCN_OK) finish(job.first, rc);
                 else flying.emplace_back(job.first, ticket);
                 if (flying.size() < 2) continue;  // look for a second batch before blocking on the first

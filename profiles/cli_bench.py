@@ -106,6 +106,8 @@ try:
         for mode, extra in modes:
             env = dict(os.environ, DCN_CLI_TIMING="1", **envs)
             out = os.path.join(d, "out.fq" + os.environ.get("DCN_CLI_OUT_EXT", ""))  # ".gz" / ".zst" / ".xz": compressed output
+            if envs.get("SLEEP_BEFORE"):  # a variant token SLEEP_BEFORE=seconds: pause between this run and the one before it
+                time.sleep(float(envs["SLEEP_BEFORE"]))
             t = time.perf_counter()
             inputs = [fq, fq] if os.environ.get("DCN_CLI_PAIRED") else [fq]  # paired: the same file as both mates
             p = subprocess.run([os.path.join(ROOT, envs.get("DCN_CLI_BIN", BIN)), "filter", idx_path, *inputs, "-o", out, "-s", os.path.join(d, "s.json"), "-q", *extra, *args],
@@ -121,7 +123,7 @@ try:
                   f"in {dt:.2f} s process wall; run() {t_wall:.3f} s = {s['bp_in']/t_wall/1e6:.0f} Mbp/s incl. index load "
                   f"({t_idx:.3f} s), {s['bp_in']/max(t_wall - t_idx, 1e-9)/1e6:.0f} Mbp/s filter only; kept {s['seqs_out']}/{s['seqs_in']}", flush=True)
             for line in p.stderr.splitlines():
-                if line.startswith("timing:"):
+                if line.startswith("timing:") or line.startswith("load timing:"):
                     print("    " + line)
 finally:
     subprocess.run(["rm", "-rf", d])

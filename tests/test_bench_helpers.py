@@ -28,12 +28,14 @@ def test_mixed_stream_is_half_long_half_short_and_interleaved():
 
 
 def test_tool_timing_lines_are_parsed():
-    err = ("timing: wall 0.782 s; busy seconds: parse 3.742 (all workers), GPU stage 0.043 (main thread waited 0.012 for it), "
+    err = ("timing: process CPU 4.095 s user + 1.544 s system\n"
+           "timing: wall 0.782 s; busy seconds: parse 3.742 (all workers), GPU stage 0.043 (main thread waited 0.012 for it), "
            "format 1.295 (all workers), write 0.000; main thread blocked pushing to format 0.001\n"
-           "timing: milestones (s): index loaded 0.298, all input parsed+queued 0.762, GPU stage drained 0.764, all written 0.765\n")
+           "timing: milestones (s): index loaded 0.298, contexts ready 0.312, all input parsed+queued 0.762, GPU stage drained 0.764, all written 0.765\n")
     t = bench_cli.parse_timing(err)
     assert t["run_wall_s"] == 0.782 and t["busy_core_s"] == {"parse": 3.742, "gpu_stage": 0.043, "format": 1.295, "write": 0.0}
     assert t["milestones_s"]["index_loaded"] == 0.298 and t["milestones_s"]["all_written"] == 0.765
+    assert t["milestones_s"]["contexts_ready"] == 0.312 and t["process_cpu_s"] == {"user": 4.095, "system": 1.544}
     assert bench_cli.parse_timing("Retained 1/2 sequences") == {}
 
 

@@ -517,6 +517,15 @@ def test_parallel_parser_on_hostile_fastq(tmp_path, oracle, monkeypatch):
         monkeypatch.setenv("DCN_CLI_NO_CHUNK_READER", "1")
         assert run("filter", idx, "-", "-t", 6, stdin=payload).stdout == out, name
         monkeypatch.delenv("DCN_CLI_NO_CHUNK_READER")
+        # the chunk parsers hand the batch over 2-bit packed (dcn_filter_batch_packed); the ASCII hand-over agrees, also
+        # when a chunk is cut into several calls (a later piece's bits are moved to base 0 of a stream of its own)
+        monkeypatch.setenv("DCN_CLI_NO_PACKED_PARSE", "1")
+        assert run("filter", idx, tmp_path / name, "-t", 6).stdout == out, name
+        monkeypatch.delenv("DCN_CLI_NO_PACKED_PARSE")
+        monkeypatch.setenv("DCN_CLI_MAX_BATCH_READS", "997")
+        assert run("filter", idx, tmp_path / name, "-t", 6).stdout == out, name
+        assert run("filter", idx, tmp_path / (name + ".gz"), "-t", 6).stdout == out, name
+        monkeypatch.delenv("DCN_CLI_MAX_BATCH_READS")
         # three ways to the same bytes: the shared output mapping (default for a plain file from a plain file: kept
         # records copied to their final place by the formatter threads), the gather writer (pipes / stdout: ranges of
         # the mapped input where a record already has its output form, formatted pieces otherwise, one writev per
@@ -681,6 +690,8 @@ def test_parser_pool_under_sanitizers(tmp_path):
              "garbage.fq": (b"@" + bytes(rng.integers(0, 256, 3_000_000, dtype=np.uint8)), False),
              "onlyat.fq": (b"@\n" * 50_000, False), "tiny.fq": (b"@a\nA\n+\nI", True)}
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    flags = open("/proc/cpuinfo").read()
+    packs = " avx2" in flags and " bmi2" in flags
     for name, (data, ok) in files.items():
         path = tmp_path / name
         path.write_bytes(data)
@@ -692,3 +703,18 @@ def test_parser_pool_under_sanitizers(tmp_path):
                 assert r.returncode == 0 and "parsed" in r.stdout, (name, t, report[-500:])
             else:
                 assert r.returncode == 1 and "Error:" in r.stderr, (name, t, report[-500:])
+        # bench-parse takes the packing parser where the host has AVX2 + BMI2 (the sequences go 2-bit packed into the batch
+        # while the records are parsed); the ASCII form stays the fallback, and --verify compares the two chunk by chunk
+        # with dcn_pack_ascii of the ASCII form as the judge, here with chunks small enough to end inside 32-base groups
+        r = subprocess.run([str(exe), "bench-parse", str(path), "-t", "3", "--ascii"], capture_output=True, text=True, env=env, timeout=300)
+        report = r.stdout + r.stderr
+        assert "AddressSanitizer" not in report and "runtime error" not in report, (name, report[-3000:])
+        assert (r.returncode == 0 and "(ascii)" in r.stdout) if ok else (r.returncode == 1 and "Error:" in r.stderr), (name, report[-500:])
+        if ok and packs:
+            r = subprocess.run([str(exe), "bench-parse", str(path), "--verify"], capture_output=True, text=True, timeout=300,
+                               env=dict(env, DCN_CLI_CHUNK_KB="256"))
+            report = r.stdout + r.stderr
+            assert "AddressSanitizer" not in report and "runtime error" not in report, (name, report[-3000:])
+            assert r.returncode == 0 and "verified" in r.stdout, (name, report[-500:])
+            if name.endswith(".fq"):
+                assert " (0 packed)" not in r.stdout, r.stdout

@@ -1330,19 +1330,36 @@ uint32_t find_cut(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t c
 
 // offsets / unit ids of reads [r0, r1): the checks of the ABI's contract, and the chunk's longest read
 int validate_chunk(const HostInput &in, uint32_t r0, uint32_t r1, uint64_t n_bases_total, uint64_t *max_len_out) {
+    // One pass over the chunk's offsets (and unit ids) on the host threads: at 10 M reads per batch the plain loop cost the
+    // submitting thread 4-5 ms of a 12 ms call, next to the pack it also waits for when the bases are pageable.
     const uint64_t *off = in.offsets;
     const uint32_t *uid = in.unit_id;
-    uint64_t max_len = 0;
-    for (uint32_t r = r0; r < r1; ++r) {
-        if (off[r + 1] < off[r] || off[r + 1] > n_bases_total) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
-        max_len = std::max(max_len, off[r + 1] - off[r]);
-    }
-    if (max_len > 0xFFFFFFF0ull) return dcn_fail(DCN_ERR_ARG, "read longer than 2^32 bases");
-    if (uid)
-        for (uint32_t r = r0 + 1; r <= r1 && r < in.n_reads; ++r)
-            if (uid[r] != uid[r - 1] && uid[r] != uid[r - 1] + 1)
-                return dcn_fail(DCN_ERR_ARG, "unit_id must stay equal or grow by one");
-    *max_len_out = max_len;
+    const uint32_t n = r1 - r0, n_reads = in.n_reads;
+    std::atomic<uint32_t> bad{0};
+    std::atomic<uint64_t> max_len{0};
+    static const bool serial = getenv("DCN_SERIAL_VALIDATE") != nullptr; // (A/B: the submitting thread alone)
+    HostPool::get().run([&](int i, int nt) {
+        const uint32_t per = (n + (uint32_t)nt - 1) / (uint32_t)nt;
+        const uint32_t a = r0 + std::min<uint64_t>(n, (uint64_t)per * (uint32_t)i), b = r0 + std::min<uint64_t>(n, (uint64_t)per * ((uint32_t)i + 1));
+        uint64_t m = 0;
+        uint32_t e = 0;
+        for (uint32_t r = a; r < b; ++r) { // (no early exit: the loop vectorises)
+            const uint64_t lo = off[r], hi = off[r + 1];
+            e |= (uint32_t)(hi < lo) | (uint32_t)(hi > n_bases_total);
+            m = std::max(m, hi - lo);
+        }
+        if (uid)
+            for (uint32_t r = a + 1; r <= b && r < n_reads; ++r) e |= (uid[r] != uid[r - 1] && uid[r] != uid[r - 1] + 1) ? 2u : 0u;
+        if (e) bad.fetch_or(e);
+        uint64_t cur = max_len.load();
+        while (m > cur && !max_len.compare_exchange_weak(cur, m)) {
+        }
+    }, n < (1u << 16) || serial);
+    const uint32_t e = bad.load();
+    if (e & 1u) return dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
+    if (max_len.load() > 0xFFFFFFF0ull) return dcn_fail(DCN_ERR_ARG, "read longer than 2^32 bases");
+    if (e & 2u) return dcn_fail(DCN_ERR_ARG, "unit_id must stay equal or grow by one");
+    *max_len_out = max_len.load();
     return DCN_OK;
 }
 

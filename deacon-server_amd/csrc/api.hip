@@ -775,34 +775,47 @@ class HostPool {
             return;
         }
         std::lock_guard<std::mutex> user(user_mu_); // one job at a time
+        fn_ = &fn;
+        pending_.store(n_threads_ - 1, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> g(mu_);
-            fn_ = &fn;
-            pending_ = n_threads_ - 1;
-            ++generation_;
+            std::lock_guard<std::mutex> g(mu_); // (under the lock: a worker about to sleep re-checks the generation under it)
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         fn(0, n_threads_);
-        std::unique_lock<std::mutex> g(mu_);
-        done_cv_.wait(g, [&] { return pending_ == 0; });
+        const auto t0 = std::chrono::steady_clock::now();
+        while (pending_.load(std::memory_order_acquire) != 0) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) {
+                std::unique_lock<std::mutex> g(mu_);
+                done_cv_.wait(g, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+                break;
+            }
+            cpu_relax();
+        }
     }
     void copy(void *dst, const void *src, size_t n) {
+        static const size_t par_min = getenv("DCN_COPY_PAR_MIN") ? (size_t)atoll(getenv("DCN_COPY_PAR_MIN")) : (size_t)4 << 20;
         run([&](int i, int nt) {
             size_t per = ((n / nt) + 4095) & ~(size_t)4095;
             size_t lo = std::min(n, per * i), hi = i == nt - 1 ? n : std::min(n, per * (i + 1));
             if (hi > lo) memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo);
-        }, n < (4u << 20));
+        }, n < par_min);
     }
     ~HostPool() {
         {
             std::lock_guard<std::mutex> g(mu_);
-            stop_ = true;
+            stop_.store(true);
         }
         cv_.notify_all();
         for (auto &t : workers_) t.join();
     }
 
   private:
+    static void cpu_relax() {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
     HostPool() {
         // CPUs this process may really use: the affinity mask, capped by the cgroup quota (a container often sees all of
         // the host's hardware threads but is throttled to a share of them); at most 12 of those
@@ -818,32 +831,43 @@ class HostPool {
         int want = (int)std::min<unsigned>(12, hw ? hw : 1);
         if (const char *e = getenv("DCN_HOST_THREADS")) want = atoi(e);
         n_threads_ = std::max(1, std::min(want, 64));
+        // A batch is a few dozen jobs a fraction of a millisecond apart (a chunk's pack, its offsets, their check): a
+        // worker that went to sleep on the condition variable after each of them paid ~0.05 ms to wake up again, three times
+        // per chunk.  It now polls the generation for a short while first (DCN_HOST_SPIN_US, default 200; 0 = sleep at once).
+        if (const char *e = getenv("DCN_HOST_SPIN_US")) spin_us_ = std::max(0, atoi(e));
         for (int i = 1; i < n_threads_; ++i) workers_.emplace_back([this, i] { worker(i); });
     }
     void worker(int i) {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void(int, int)> *fn;
-            {
-                std::unique_lock<std::mutex> g(mu_);
-                cv_.wait(g, [&] { return stop_ || generation_ != seen; });
-                if (stop_) return;
-                seen = generation_;
-                fn = fn_;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (generation_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) {
+                    std::unique_lock<std::mutex> g(mu_);
+                    cv_.wait(g, [&] { return stop_.load() || generation_.load(std::memory_order_acquire) != seen; });
+                    break;
+                }
+                cpu_relax();
             }
+            if (stop_.load()) return;
+            seen = generation_.load(std::memory_order_acquire);
+            const std::function<void(int, int)> *fn = fn_;
             (*fn)(i, n_threads_);
-            std::lock_guard<std::mutex> g(mu_);
-            if (--pending_ == 0) done_cv_.notify_one();
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> g(mu_);
+                done_cv_.notify_one();
+            }
         }
     }
     int n_threads_ = 1;
+    int spin_us_ = 200;
     std::vector<std::thread> workers_;
     std::mutex mu_, user_mu_;
     std::condition_variable cv_, done_cv_;
     const std::function<void(int, int)> *fn_ = nullptr;
-    int pending_ = 0;
-    uint64_t generation_ = 0;
-    bool stop_ = false;
+    std::atomic<int> pending_{0};
+    std::atomic<uint64_t> generation_{0};
+    std::atomic<bool> stop_{false};
 };
 
 // page-locked host memory (hipHostMalloc / hipHostRegister, e.g. from dcn_host_alloc) needs no staging
@@ -1375,7 +1399,9 @@ int chunk_events(dcn_slot &sl, size_t n) {
 }
 
 // kernels + result copies of one chunk (its inputs are on the device, or on their way on the copy stream)
-int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d) {
+// n_known: the batch's chunks are all in sl.chunks (false while a host-bound submission is still cutting them: the
+// decisions then go back in one copy behind the last chunk)
+int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d, bool n_known = true, bool is_last = false) {
     const dcn_chunk &ch = sl.chunks[ci];
     if (wait_h2d) DCN_HIP(hipStreamWaitEvent(c->stream, sl.ev_h2d[ci], 0));
     BatchView v;
@@ -1402,8 +1428,8 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d) {
     // the last chunk is still on the link, and the last chunk's own (a 10 M-read call otherwise ends with 10 MB crossing
     // the link back after everything else is done: 0.2 ms of its 12.4 ms).
     const size_t n_ch = sl.chunks.size();
-    const bool last = ci + 1 == n_ch;
-    const bool split = !sl.counts && n_ch >= 4, early = split && ci + 2 == n_ch;
+    const bool last = n_known ? ci + 1 == n_ch : is_last;
+    const bool split = n_known && !sl.counts && n_ch >= 4, early = split && ci + 2 == n_ch;
     if (!sl.counts && !last && !early) return DCN_OK;
     DCN_HIP(hipEventRecord(sl.ev_comp[ci], c->stream));
     DCN_HIP(hipStreamWaitEvent(c->d2h_stream, sl.ev_comp[ci], 0));
@@ -1496,6 +1522,16 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     // twice the chunk size then (packed input, two in flight: 105 -> 120 Gbp/s when the host was the limit).
     static const uint64_t inflight_factor = getenv("DCN_INFLIGHT_CHUNK_FACTOR") ? strtoull(getenv("DCN_INFLIGHT_CHUNK_FACTOR"), nullptr, 10) : 2;
     const uint64_t chunk_bases = c->chunk_bases * (slots_busy(c) ? std::max<uint64_t>(inflight_factor, 1) : 1);
+    // DCN_SUBMIT_TIMING=1: where the submitting thread's time goes, one line per call on stderr
+    static const bool submit_timing = getenv("DCN_SUBMIT_TIMING") != nullptr;
+    double tm[6] = {0, 0, 0, 0, 0, 0}; // stage wait, pack, copy calls, offsets / unit ids, validate, kernels
+    const auto t_submit0 = std::chrono::steady_clock::now();
+    auto lap = [&](int which, std::chrono::steady_clock::time_point &t) {
+        if (!submit_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        tm[which] += std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+    };
     for (int attempt = 0;; ++attempt) {
         sl.device_pack = tr == Transport::AsciiDirect || tr == Transport::AsciiStaged;
         sl.chunks.clear();
@@ -1507,6 +1543,8 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
             rc = staged_h2d(c, sl.d_unit_id, in.unit_id, (uint64_t)n_reads * sizeof(uint32_t), 1);
         uint32_t r0 = 0, u0 = 0;
         uint64_t groups_done = 0; // 32-base groups of the stream already sent (HostPacked / Packed)
+        static const bool no_interleave = getenv("DCN_NO_INTERLEAVE") != nullptr, no_ride = getenv("DCN_NO_RIDE") != nullptr; // (A/B)
+        const bool interleave = (tr == Transport::HostPacked || tr == Transport::AsciiStaged) && !no_interleave;
         while (r0 < n_reads && rc == DCN_OK) {
             dcn_chunk ch;
             ch.r0 = r0;
@@ -1519,6 +1557,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                 rc = dcn_fail(DCN_ERR_ARG, "offsets must be non-decreasing");
                 break;
             }
+            bool rode = false; // this chunk's pageable offsets / unit ids went with its packed piece
             auto copies = [&]() -> int {
                 if (ch.b1 > ch.b0) {
                     if (sl.device_pack) {
@@ -1538,14 +1577,29 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                                 // pieces of whole groups: 8 bytes of stream + 4 of mask per group, side by side in a
                                 // staging buffer, packed there by the host threads
                                 const uint64_t per_piece = c->stage_bytes / 12 / 64 * 64;
+                                // pageable offsets (and unit ids) of the chunk ride in the same staging buffer when they fit
+                                // behind its one piece, copied by the threads that pack it: no ring slot, no job and no
+                                // copy by the submitting thread of their own (3.5 MB per 64 Mbp chunk of 150 bp reads:
+                                // 3.7 ms of a 10 M-read call)
+                                const uint64_t n_off = (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t);
+                                const uint64_t n_uid = (in.unit_id && !uid_pinned) ? (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t) : 0;
+                                const bool ride = !off_pinned && !no_ride && g1 - g0 <= per_piece && 12 * (g1 - g0) + 16 + n_off + n_uid <= c->stage_bytes;
                                 for (uint64_t g = g0; g < g1; g += per_piece) {
                                     const uint64_t m = std::min<uint64_t>(per_piece, g1 - g);
                                     const int which = c->stage_next;
                                     c->stage_next = (which + 1) % dcn_ctx::N_STAGE;
+                                    auto tl = std::chrono::steady_clock::now();
                                     DCN_HIP(hipEventSynchronize(c->stage_free[which]));
+                                    lap(0, tl);
                                     uint32_t *hp = (uint32_t *)c->h_stage[which], *hm = hp + 2 * m;
+                                    uint8_t *ho = (uint8_t *)(((uintptr_t)(hm + m) + 7) & ~(uintptr_t)7), *hu = ho + n_off;
                                     std::atomic<bool> nl(false);
                                     HostPool::get().run([&](int i, int nt) {
+                                        if (ride) {
+                                            const uint64_t o0 = n_off * i / nt, o1 = n_off * (i + 1) / nt, q0 = n_uid * i / nt, q1 = n_uid * (i + 1) / nt;
+                                            memcpy(ho + o0, (const uint8_t *)(in.offsets + ch.r0) + o0, o1 - o0);
+                                            if (n_uid) memcpy(hu + q0, (const uint8_t *)(in.unit_id + ch.r0) + q0, q1 - q0);
+                                        }
                                         const uint64_t per = (m + nt - 1) / nt, lo = std::min<uint64_t>(m, per * i),
                                                        hi = std::min<uint64_t>(m, lo + per);
                                         if (hi <= lo) return;
@@ -1554,10 +1608,17 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                                         if (dcn_host_pack_groups(in.bases, n_bases, g + lo, g + hi, hp + 2 * lo, hm + lo))
                                             nl.store(true);
                                     }, m < 4096);
+                                    lap(1, tl);
                                     saw_newline = saw_newline || nl.load();
                                     DCN_HIP(hipMemcpyAsync(dp + 2 * (g - g0), hp, m * 8, hipMemcpyHostToDevice, c->copy_stream));
                                     DCN_HIP(hipMemcpyAsync(dm + (g - g0), hm, m * 4, hipMemcpyHostToDevice, c->copy_stream));
+                                    if (ride) {
+                                        DCN_HIP(hipMemcpyAsync(sl.d_offsets + ch.r0, ho, n_off, hipMemcpyHostToDevice, c->copy_stream));
+                                        if (n_uid) DCN_HIP(hipMemcpyAsync(sl.d_unit_id + ch.r0, hu, n_uid, hipMemcpyHostToDevice, c->copy_stream));
+                                        rode = true;
+                                    }
                                     DCN_HIP(hipEventRecord(c->stage_free[which], c->copy_stream));
+                                    lap(2, tl);
                                 }
                             }
                             groups_done = g1;
@@ -1566,16 +1627,21 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                 }
                 // page-locked offsets / unit ids went over in one copy each before the first chunk (two runtime calls
                 // less per chunk); pageable ones are staged chunk by chunk
-                if (!off_pinned)
+                auto to = std::chrono::steady_clock::now();
+                if (!off_pinned && !rode)
                     DCN_TRY(staged_h2d(c, sl.d_offsets + ch.r0, in.offsets + ch.r0, (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t), 0));
-                if (in.unit_id && !uid_pinned)
+                if (in.unit_id && !uid_pinned && !rode)
                     DCN_TRY(staged_h2d(c, sl.d_unit_id + ch.r0, in.unit_id + ch.r0, (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t), 0));
+                lap(3, to);
                 return DCN_OK;
             };
             if ((rc = copies()) != DCN_OK) break;
             if (saw_newline) break; // this attempt is abandoned
             // validated while the copies above are in flight; the kernels are only queued in the second pass
-            if ((rc = validate_chunk(in, ch.r0, ch.r1, n_bases, &ch.max_len)) != DCN_OK) break;
+            auto tv = std::chrono::steady_clock::now();
+            rc = validate_chunk(in, ch.r0, ch.r1, n_bases, &ch.max_len);
+            lap(4, tv);
+            if (rc != DCN_OK) break;
             if (ch.u1 < ch.u0 || (uint64_t)ch.u1 - ch.u0 > (uint64_t)ch.r1 - ch.r0) {
                 rc = dcn_fail(DCN_ERR_ARG, "unit_id must stay equal or grow by one");
                 break;
@@ -1589,10 +1655,24 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
             }
             r0 = ch.r1;
             u0 = ch.u1;
+            if (interleave && sl.chunks.size() >= 2) { // the chunk before this one: its copies are queued, it is not the last
+                auto tk = std::chrono::steady_clock::now();
+                rc = enqueue_chunk(c, sl, sl.chunks.size() - 2, true, false, false);
+                lap(5, tk);
+            }
         }
         // second pass: the kernels.  Every copy is already queued, so the link never waits for the host to get round
-        // to the next chunk (a chunk's ~15 runtime calls cost about as much host time as its copy takes on the link)
-        for (size_t ci = 0; rc == DCN_OK && !saw_newline && ci < sl.chunks.size(); ++ci) rc = enqueue_chunk(c, sl, ci, true);
+        // to the next chunk (a chunk's ~15 runtime calls cost about as much host time as its copy takes on the link).
+        // Where the HOST is the slower side (it packs or stages pageable bases chunk by chunk) the kernels of a chunk are
+        // queued as soon as the next chunk's copies are, one chunk behind, instead: they then run under the packing of
+        // the chunks that follow, not after it (a blocking 10 M-read call of pageable bases: 19.3 -> 15 ms).
+        auto tk = std::chrono::steady_clock::now();
+        if (interleave) {
+            if (rc == DCN_OK && !saw_newline && !sl.chunks.empty()) rc = enqueue_chunk(c, sl, sl.chunks.size() - 1, true, false, true);
+        } else {
+            for (size_t ci = 0; rc == DCN_OK && !saw_newline && ci < sl.chunks.size(); ++ci) rc = enqueue_chunk(c, sl, ci, true);
+        }
+        lap(5, tk);
 
         n_units = u0;
         if (rc == DCN_OK && saw_newline && attempt == 0) {
@@ -1612,6 +1692,10 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         drain(c);
         return rc;
     }
+    if (submit_timing)
+        fprintf(stderr, "submit timing: %.2f ms, %zu chunks: stage wait %.2f, pack %.2f, copy calls %.2f, offsets / unit ids %.2f, validate %.2f, "
+                        "kernels %.2f\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_submit0).count(),
+                sl.chunks.size(), tm[0], tm[1], tm[2], tm[3], tm[4], tm[5]);
     sl.busy = true;
     sl.ticket = c->next_ticket++;
     *ticket = sl.ticket;

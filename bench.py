@@ -793,6 +793,10 @@ def main():
                     help="which of the extra measurements to run (comma separated)")
     args = ap.parse_args()
 
+    # torch sizes its CPU thread pool by the machine (256 hardware threads on the GPU box) while the job's CPU quota is a
+    # 16th of it: one parallel CPU op would spend the quota of its 100 ms period at once and the host legs that follow
+    # would be measured throttled (cpu.stat: nr_throttled)
+    torch.set_num_threads(max(1, min(host_cores(), torch.get_num_threads())))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

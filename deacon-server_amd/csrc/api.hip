@@ -839,10 +839,15 @@ class HostPool {
     }
     void worker(int i) {
         uint64_t seen = 0;
+        int streak = 0; // jobs in a row that came within the polling window of their predecessor
         for (;;) {
+            // polls only while jobs keep coming that closely (a submission: a chunk's pack, its check, the next chunk's
+            // pack ...); the tool's staging copies, one or two per half millisecond, would only burn the parsers' CPUs
+            // (measured: 2.3 core-seconds of a 0.9 s run)
             const auto t0 = std::chrono::steady_clock::now();
+            const auto window = std::chrono::microseconds(streak >= 2 ? spin_us_ : 0);
             while (generation_.load(std::memory_order_acquire) == seen && !stop_.load(std::memory_order_relaxed)) {
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) {
+                if (std::chrono::steady_clock::now() - t0 >= window) {
                     std::unique_lock<std::mutex> g(mu_);
                     cv_.wait(g, [&] { return stop_.load() || generation_.load(std::memory_order_acquire) != seen; });
                     break;
@@ -850,6 +855,7 @@ class HostPool {
                 cpu_relax();
             }
             if (stop_.load()) return;
+            streak = std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_) ? std::min(streak + 1, 2) : 0;
             seen = generation_.load(std::memory_order_acquire);
             const std::function<void(int, int)> *fn = fn_;
             (*fn)(i, n_threads_);

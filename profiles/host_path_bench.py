@@ -14,6 +14,8 @@ import torch  # noqa: F401  (load torch's HIP runtime first)
 sys.path.insert(0, ".")
 import deacon_server_amd as dcn  # noqa: E402
 
+torch.set_num_threads(min(16, torch.get_num_threads()))  # (the CPU quota of a 1-GPU job, not the machine's 256 threads)
+
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 n_keys = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
 calls = int(sys.argv[3]) if len(sys.argv) > 3 else 12

@@ -848,6 +848,37 @@ __attribute__((target("avx2"))) inline size_t line_end_avx2(const char *d, size_
 }
 #endif
 
+#if defined(__x86_64__)
+// the same with 64 bytes per compare where the host has AVX-512BW (a 150-byte line: three steps instead of five); bytes at
+// or past `size` are never loaded (masked load)
+__attribute__((target("avx512f,avx512bw"))) inline size_t line_end_avx512(const char *d, size_t size, size_t p) {
+    const __m512i nl = _mm512_set1_epi8('\n');
+    size_t q = p;
+    for (int i = 0; i < 3; ++i, q += 64) {
+        if (q + 64 <= size) {
+            const uint64_t m = _mm512_cmpeq_epi8_mask(_mm512_loadu_si512((const void *)(d + q)), nl);
+            if (m) return q + (size_t)__builtin_ctzll(m);
+        } else {
+            if (q >= size) return size;
+            const __mmask64 k = (~0ull) >> (64 - (size - q));
+            const uint64_t m = _mm512_cmpeq_epi8_mask(_mm512_maskz_loadu_epi8(k, (const void *)(d + q)), nl) & k;
+            return m ? q + (size_t)__builtin_ctzll(m) : size;
+        }
+    }
+    return line_end(d, size, q);
+}
+#endif
+
+inline bool cli_avx512() {
+#if defined(__x86_64__)
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && !std::getenv("DCN_CLI_NO_AVX2") &&
+                           !std::getenv("DCN_CLI_NO_AVX512");
+    return ok;
+#else
+    return false;
+#endif
+}
+
 // The batch stream written in the library's packed form while the records are parsed (dcn_filter_batch_packed,
 // include/deacon_hip.h: base i = bits [2(i%32), +2) of the i/32-th 64-bit word, code (c >> 1) & 3; invalid bit i%32 of
 // mask word i/32 set iff the byte is not one of ACGTacgt -- PackedSeqVec::from_ascii and the mask loop of
@@ -862,6 +893,7 @@ struct PackSink {
     unsigned fill = 0;  // bases in the accumulator, 0..31
     size_t g = 0;       // groups stored so far
     bool multi = false; // a record whose sequence spans several lines was met (its formatter needs contiguous bases)
+    bool wide = cli_avx512();
 
     inline void put(uint64_t v, uint32_t m, unsigned n) {  // n <= 32 bases, bits above them zero
         accP |= v << (2 * fill);
@@ -909,6 +941,31 @@ struct PackSink {
 #else
     void push(const char *, size_t, const char *) {}
 #endif
+#if defined(__x86_64__)
+    // 64 bases per step (AVX-512BW): the codes folded by two multiply-adds and narrowed out of their dwords, the invalid
+    // bits out of four byte compares as one 64-bit mask (csrc/host_pack.cpp has the same arithmetic for whole buffers);
+    // a masked load takes the last, partial step, so nothing behind the line is touched
+    __attribute__((target("avx512f,avx512bw"))) void push512(const char *s, size_t n) {
+        const __m512i three = _mm512_set1_epi8(3), lower = _mm512_set1_epi8(0x20);
+        const __m512i m14 = _mm512_set1_epi16(0x0401), m116 = _mm512_set1_epi32(0x00100001);
+        const __m512i ca = _mm512_set1_epi8('a'), cc = _mm512_set1_epi8('c'), cg = _mm512_set1_epi8('g'), ct = _mm512_set1_epi8('t');
+        for (size_t i = 0; i < n; i += 64) {
+            const unsigned m = n - i < 64 ? (unsigned)(n - i) : 64u;
+            const __mmask64 k = (~0ull) >> (64 - m);
+            const __m512i v = m == 64 ? _mm512_loadu_si512((const void *)(s + i)) : _mm512_maskz_loadu_epi8(k, (const void *)(s + i));
+            const __m512i code = _mm512_and_si512(_mm512_srli_epi16(v, 1), three);  // (zero bytes give code 0)
+            const __m128i q = _mm512_cvtepi32_epi8(_mm512_madd_epi16(_mm512_maddubs_epi16(code, m14), m116));
+            const __m512i l = _mm512_or_si512(v, lower);
+            const uint64_t ok = _mm512_cmpeq_epi8_mask(l, ca) | _mm512_cmpeq_epi8_mask(l, cc) | _mm512_cmpeq_epi8_mask(l, cg) |
+                                _mm512_cmpeq_epi8_mask(l, ct);
+            const uint64_t inv = ~ok & k;
+            put((uint64_t)_mm_cvtsi128_si64(q), (uint32_t)inv, m < 32 ? m : 32u);
+            if (m > 32) put((uint64_t)_mm_extract_epi64(q, 1), (uint32_t)(inv >> 32), m - 32);
+        }
+    }
+#else
+    void push512(const char *, size_t) {}
+#endif
     size_t finish() {  // stores the last, partial group (bits behind the stream's end stay zero: 'A', valid); groups written
         if (fill) {
             std::memcpy(P + 2 * g, &accP, 8);
@@ -939,7 +996,7 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
                                   PackSink *ps = nullptr) {
     auto eol = [&](size_t q) {
 #if defined(__x86_64__)
-        if (AVX2) return line_end_avx2(d, b, q);
+        if (AVX2) return cli_avx512() ? line_end_avx512(d, b, q) : line_end_avx2(d, b, q);
 #endif
         return line_end(d, b, q);
     };
@@ -961,7 +1018,7 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
         size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
         if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
         if (MODE == 1) std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
-        if (MODE == 2) ps->push(d + s1, t1 - s1, d + b), r.seq_off = shift + s1;
+        if (MODE == 2) (ps->wide ? ps->push512(d + s1, t1 - s1) : ps->push(d + s1, t1 - s1, d + b)), r.seq_off = shift + s1;
         nb += t1 - s1;
         r.qual_off = shift + s3;
         if (t1 == e1 && t3 == e3 && e2 == s2 + 1 && e3 < b && r.id_len == e0 - (p + 1) && e3 + 1 - p < (1ull << 32)) {
@@ -977,7 +1034,7 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
             size_t e = eol(q);
             cr = cr || trim(q, e) != e;
             if (MODE == 1) std::memcpy(bases + nb, d + q, trim(q, e) - q);
-            if (MODE == 2) ps->push(d + q, trim(q, e) - q, d + b);
+            if (MODE == 2) (ps->wide ? ps->push512(d + q, trim(q, e) - q) : ps->push(d + q, trim(q, e) - q, d + b));
             nb += trim(q, e) - q;
             q = e + 1;
             last_e = e;
@@ -2024,6 +2081,7 @@ int run_filter(const FilterArgs &a) {
         if (getrusage(RUSAGE_SELF, &ru) == 0)  // every thread of the process, the library's host threads and the runtime's included
             std::fprintf(stderr, "timing: process CPU %.3f s user + %.3f s system\n", ru.ru_utime.tv_sec + ru.ru_utime.tv_usec * 1e-6,
                          ru.ru_stime.tv_sec + ru.ru_stime.tv_usec * 1e-6);
+
     }
     if (cli_timing)
         std::fprintf(stderr, "timing: wall %.3f s; busy seconds: parse %.3f (all workers), GPU stage %.3f (main thread waited %.3f for it), "
@@ -2272,10 +2330,11 @@ int main(int argc, char **argv) {
         }
         if (args[0] == "bench-parse" && args.size() >= 2) {  // hidden: the parser pool alone on a plain FASTX file (no GPU)
             size_t threads = 8;
-            bool packed = cli_can_pack(), verify = false;
+            bool packed = cli_can_pack(), verify = false, count_only = false;
             for (size_t i = 2; i < args.size(); ++i) {
                 if (args[i] == "-t" && i + 1 < args.size()) threads = (size_t)std::atoll(args[++i].c_str());
                 else if (args[i] == "--ascii") packed = false;
+                else if (args[i] == "--count") count_only = true;  // the record walk alone: no sequence copy, no Rec kept
                 else if (args[i] == "--verify") verify = true;  // both forms of every chunk, compared (dcn_pack_ascii as the judge)
             }
             MappedFile mf;
@@ -2324,6 +2383,10 @@ int main(int argc, char **argv) {
                 pool.emplace_back([&] {
                     Batch b;  // recycled, as the pipeline's pool does
                     for (size_t i; (i = next.fetch_add(1)) < chunks.size();) {
+                        if (count_only) {
+                            recs += count_mapped_records(mf.data, chunks[i].first, chunks[i].second, fq);
+                            continue;
+                        }
                         b.clear();
                         parse_mapped_chunk(mf.data, chunks[i].first, chunks[i].second, fq, b, packed);
                         recs += b.recs.size();

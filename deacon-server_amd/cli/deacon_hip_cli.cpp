@@ -2330,16 +2330,30 @@ int main(int argc, char **argv) {
         }
         if (args[0] == "bench-parse" && args.size() >= 2) {  // hidden: the parser pool alone on a plain FASTX file (no GPU)
             size_t threads = 8;
-            bool packed = cli_can_pack(), verify = false, count_only = false;
+            bool packed = cli_can_pack(), verify = false, count_only = false, prefault = false;
             for (size_t i = 2; i < args.size(); ++i) {
                 if (args[i] == "-t" && i + 1 < args.size()) threads = (size_t)std::atoll(args[++i].c_str());
                 else if (args[i] == "--ascii") packed = false;
                 else if (args[i] == "--count") count_only = true;  // the record walk alone: no sequence copy, no Rec kept
+                else if (args[i] == "--prefault") prefault = true;  // experiment: MADV_POPULATE_READ of the whole mapping on all threads, before the clock starts
                 else if (args[i] == "--verify") verify = true;  // both forms of every chunk, compared (dcn_pack_ascii as the judge)
             }
             MappedFile mf;
             if (!mf.open(args[1])) die("cannot map " + args[1]);
             const bool fq = mf.data[0] == '@';
+#ifdef MADV_POPULATE_READ
+            if (prefault) {
+                auto tp = std::chrono::steady_clock::now();
+                const size_t slice = 8u << 20, n_slices = (mf.size + slice - 1) / slice;
+                parallel_for(n_slices, threads, [&](size_t i) {
+                    const uintptr_t lo = ((uintptr_t)mf.data + i * slice) & ~(uintptr_t)4095;
+                    const uintptr_t hi = ((uintptr_t)mf.data + std::min(mf.size, (i + 1) * slice) + 4095) & ~(uintptr_t)4095;
+                    if (madvise((void *)lo, hi - lo, MADV_POPULATE_READ) != 0) std::perror("madvise");
+                });
+                std::printf("populated %.2f GB in %.3f s on %zu threads\n", mf.size / 1e9,
+                            std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count(), threads);
+            }
+#endif
             auto t0 = std::chrono::steady_clock::now();
             std::vector<std::pair<size_t, size_t>> chunks;
             size_t chunk = std::min<size_t>(std::max<size_t>(mf.size / (4 * threads), 4u << 20), 24u << 20);

@@ -861,7 +861,7 @@ def main():
     if world > 1 and not args.no_extras and args.workload == "short":
         try:
             host_path_all = run_host_path(index, batches, params, None, host_cores(), calls=4, reads_per_call=args.reads,
-                                          kinds=("pinned", "packed"), reps=3, world=world, rank=rank, coll_device=coll_device)
+                                          kinds=("pageable", "pinned", "packed"), reps=3, world=world, rank=rank, coll_device=coll_device)
         except Exception as ex:  # every rank fails or none does (same code, same sizes); never take the line with it
             log(f"host_path at N = {world} failed: {ex!r}")
             host_path_all = {"error": repr(ex)}

@@ -1259,6 +1259,7 @@ extern "C" int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, con
 // ----------------------------------------------------------------------------------------------------
 // host batches: submit / wait
 // ----------------------------------------------------------------------------------------------------
+bool dcn_host_pack_is_wide();
 bool dcn_host_pack_groups(const uint8_t *ascii, uint64_t n_bases, uint64_t g0, uint64_t g1, uint32_t *packed,
                           uint32_t *mask); // host_pack.cpp; true: a '\n' byte was seen
 
@@ -1501,9 +1502,14 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         if (n_bases > 0 && packed_in && !in.invmask) return dcn_fail(DCN_ERR_ARG, "invmask is NULL");
     }
     const bool host_pack_ok = !getenv("DCN_NO_HOST_PACK"); // read per call: tests switch it
+    // Page-locked ASCII can cross the link as it is (1 byte per base, no host work: 52-53 Gbp/s) or be packed by the host
+    // threads like pageable ASCII (0.375 bytes per base: 90-110 Gbp/s where they pack with AVX-512, csrc/host_pack.cpp).
+    // The faster one is taken; DCN_PINNED_ASCII_DMA=1 keeps the host out of it.
+    const bool bases_pinned = is_pinned_host(in.bases);
+    const bool pinned_dma = bases_pinned && (!host_pack_ok || !dcn_host_pack_is_wide() || getenv("DCN_PINNED_ASCII_DMA"));
     Transport tr;
     if (in.packed) tr = Transport::Packed;
-    else if (is_pinned_host(in.bases)) tr = Transport::AsciiDirect;
+    else if (pinned_dma) tr = Transport::AsciiDirect;
     else tr = host_pack_ok ? Transport::HostPacked : Transport::AsciiStaged;
 
     sl.params = *params;
@@ -1683,7 +1689,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         n_units = u0;
         if (rc == DCN_OK && saw_newline && attempt == 0) {
             drain(c);
-            tr = Transport::AsciiStaged;
+            tr = bases_pinned ? Transport::AsciiDirect : Transport::AsciiStaged;
             continue;
         }
         if (rc != DCN_OK) {

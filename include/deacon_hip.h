@@ -181,11 +181,13 @@ void dcn_ctx_destroy(dcn_ctx *ctx);
  *
  * Blocking (= dcn_filter_batch_submit + dcn_filter_batch_wait).  Inside, the batch is cut at unit boundaries into
  * chunks of ~64 Mbp (DCN_CHUNK_BASES): chunk i's kernels run while chunk i+1 crosses PCIe on a side stream and chunk i-1's results
- * travel back on a third.  What crosses the link depends on where `bases` lives:
- *   page-locked memory (dcn_host_alloc / hipHostRegister)  the ASCII is DMA'd as it is and packed on the device;
+ * travel back on a third.  What crosses the link:
  *   pageable memory   host threads pack it to 2 bits + 1 mask bit per base straight into the context's pinned
  *                     staging ring (0.375 instead of 1 byte per base on the link -- the reference packs on the host
- *                     too: src/filter_common.rs:238-258).
+ *                     too: src/filter_common.rs:238-258);
+ *   page-locked memory (dcn_host_alloc / hipHostRegister)  the same where the host packs fast enough to beat the
+ *                     link's 1 byte per base (AVX-512BW hosts), else -- and always with DCN_PINNED_ASCII_DMA=1 -- the
+ *                     ASCII is DMA'd as it is and packed on the device (no host work at all).
  * A batch that needed more hit-record scratch than the context has is re-run after growing it: callers never see
  * DCN_ERR_CAPACITY for that. */
 int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,

@@ -50,14 +50,17 @@ def assert_same(got, want):
     assert got[0].tolist() == want[0].tolist(), "keep decisions differ"
 
 
-@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("pinned", [False, True, "dma"])
 @pytest.mark.parametrize("paired", [False, True])
 def test_chunked_batch_matches_oracle(oracle, dcn, genome, index_pair, monkeypatch, pinned, paired):
-    """a batch cut into dozens of chunks (pageable: host-packed into the staging ring; page-locked: ASCII DMA +
-    device pack) gives the oracle's results, chunk seams inside and between units included"""
+    """a batch cut into dozens of chunks (pageable: host-packed into the staging ring; page-locked: the same where the
+    host packs with AVX-512, else -- and always with DCN_PINNED_ASCII_DMA, the "dma" case -- ASCII DMA + device pack)
+    gives the oracle's results, chunk seams inside and between units included"""
     small_chunks(monkeypatch)
+    if pinned == "dma":
+        monkeypatch.setenv("DCN_PINNED_ASCII_DMA", "1")
     oidx, gidx = index_pair
-    rng = np.random.default_rng(102 + pinned + 2 * paired)
+    rng = np.random.default_rng(102 + bool(pinned) + 2 * paired)
     reads = mixed_reads(rng, genome)
     b, o = oracle.concat_reads(reads)
     uid = (np.arange(len(reads)) // 2).astype(np.uint32) if paired else None

@@ -691,8 +691,16 @@ def run_host_path(index, batches, params, oidx, cores, calls=6, reads_per_call=1
         dcn._native.check(rc)
         return t.value
 
-    link_bytes = {"pageable": 0.375 * n_bases + 8 * n_reads, "pinned": 1.0 * n_bases + 8 * n_reads,
+    # page-locked ASCII is packed by the host threads as well where they do it with AVX-512 (csrc/api.hip, submit_impl):
+    # 0.375 bytes per base on the link then, 1 when it is sent as it is
+    try:
+        wide_pack = (" avx512bw" in open("/proc/cpuinfo").read() and not os.environ.get("DCN_NO_AVX512")
+                     and not os.environ.get("DCN_PINNED_ASCII_DMA") and not os.environ.get("DCN_NO_HOST_PACK"))
+    except OSError:
+        wide_pack = False
+    link_bytes = {"pageable": 0.375 * n_bases + 8 * n_reads, "pinned": (0.375 if wide_pack else 1.0) * n_bases + 8 * n_reads,
                   "packed": 0.375 * n_bases + 8 * n_reads}
+    out["pinned_ascii_transport"] = "packed by the host threads (AVX-512)" if wide_pack else "sent as it is, packed on the device"
 
     def wait(tk):
         dcn._native.check(lib.dcn_filter_batch_wait(proc._h, tk))

@@ -18,6 +18,7 @@
 // Input/output compression: gzip via zlib; zstd and xz through the installed runtime libraries (codecs.hpp).
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sched.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
@@ -1603,6 +1604,21 @@ struct StageClock {
     double seconds() const { return ns.load() * 1e-9; }
 };
 
+// CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (a container often sees every
+// hardware thread of its host and is throttled to a share of them)
+size_t usable_cpus() {
+    size_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<size_t>(n, (size_t)std::max(1, CPU_COUNT(&set)));
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            n = std::min<size_t>(n, (size_t)std::max<long long>(1, quota / period));
+        std::fclose(f);
+    }
+    return n;
+}
+
 // ---- deacon filter (src/local_filter.rs:575-824) ---------------------------------------------------------------
 int run_filter(const FilterArgs &a) {
     StageClock t_parse, t_gpu, t_gpu_wait, t_format, t_write, t_push_wait;
@@ -1685,7 +1701,7 @@ int run_filter(const FilterArgs &a) {
     // ---- stage 1: parsed batches, in input order --------------------------------------------------------------
     // plain regular file, single input: mmap + parallel parsing of record-aligned chunks; otherwise (stdin, gzip,
     // paired) one streaming reader thread
-    size_t n_workers = a.threads ? a.threads : std::max(1u, std::thread::hardware_concurrency());
+    size_t n_workers = a.threads ? a.threads : usable_cpus();  // -t 0: every CPU this process may really use
     n_workers = std::min<size_t>(std::max<size_t>(n_workers, 1), 64);
     bool fastq_in = parallel_in && mapped.data[0] == '@';
     if (parallel_in && mapped.data[0] != '@' && mapped.data[0] != '>') die("Invalid FASTX record start: expected '>' or '@'");

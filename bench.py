@@ -815,10 +815,13 @@ def main():
     # rehearsal of the N > 1 path on a one-GPU box (profiles/rehearse_two_ranks.sh): every rank on GPU 0, collectives
     # on gloo (RCCL does not take two ranks on one device).  The driver's scaling run uses neither variable.
     backend = os.environ.get("DCN_BENCH_BACKEND", "nccl")
-    # N > 1: this rank's host threads (the library's packers, result copies, torch) go to the cores next to its GPU, before
-    # anything touches the GPU or starts a thread pool -- eight ranks share one host's memory and PCIe root complexes
+    # This rank's host threads (the library's packers, result copies, torch, the tool's child processes) go to the cores next
+    # to its GPU, before anything touches the GPU or starts a thread pool: at N > 1 eight ranks share one host's memory and
+    # PCIe root complexes, and at N = 1 a job whose threads roam over both sockets of the box packs and stages half of its
+    # bytes across the socket link (same box, host legs from pageable memory: 76-83 Gbp/s unbound, 100-108 bound;
+    # page-locked ASCII 104-116 -> 119-120).  DCN_BENCH_NO_BIND=1 leaves the affinity alone.
     binding = None
-    if world > 1 and not os.environ.get("DCN_BENCH_NO_BIND"):
+    if not os.environ.get("DCN_BENCH_NO_BIND"):
         lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
         binding = dcn.distributed.bind_rank_to_gpu_cpus(local_rank, lw, gpu_of_rank=[0] * lw if os.environ.get("DCN_BENCH_SINGLE_DEVICE") else None)
     if os.environ.get("DCN_BENCH_SINGLE_DEVICE"):

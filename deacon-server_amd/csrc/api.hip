@@ -336,6 +336,10 @@ struct dcn_slot {
     uint8_t *d_ascii = nullptr;
     uint32_t *d_packed = nullptr, *d_invmask = nullptr;
     uint64_t *d_offsets = nullptr;
+    // offsets of a batch of < 2^32 bases cross the link as u32 (4 instead of 8 bytes per read: 6 % of a packed call's bytes)
+    // and are widened into d_offsets by a kernel in front of each chunk's own kernels
+    uint32_t *d_off32 = nullptr, *h_off32 = nullptr;
+    bool off32 = false;
     uint32_t *d_unit_id = nullptr;
     uint8_t *d_keep = nullptr;
     uint32_t *d_hits = nullptr, *d_total = nullptr;
@@ -462,7 +466,8 @@ void free_slot_buffers(dcn_slot &sl) {
             if (p) hipFree(p);
     }
     if (sl.d_report) hipFree(sl.d_report);
-    void *host[] = {sl.h_keep, sl.h_hits, sl.h_total, sl.h_report};
+    if (sl.d_off32) hipFree(sl.d_off32);
+    void *host[] = {sl.h_keep, sl.h_hits, sl.h_total, sl.h_report, sl.h_off32};
     for (void *p : host)
         if (p) hipHostFree(p);
     if (sl.done) hipEventDestroy(sl.done);
@@ -1320,6 +1325,7 @@ int alloc_slot_impl(dcn_ctx *c, int si) {
         DCN_HIP(hipDeviceSynchronize()); // the null-stream memsets must not overtake this slot's first copies
     }
     DCN_TRY(dev_alloc(&sl.d_report, 1, "slot report"));
+    DCN_TRY(dev_alloc(&sl.d_off32, MR + 1, "slot offsets (u32)"));
     DCN_HIP(hipHostMalloc((void **)&sl.h_report, sizeof(dcn_batch_report), hipHostMallocDefault));
     DCN_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     sl.allocated = true;
@@ -1360,7 +1366,14 @@ uint32_t find_cut(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t c
 }
 
 // offsets / unit ids of reads [r0, r1): the checks of the ABI's contract, and the chunk's longest read
-int validate_chunk(const HostInput &in, uint32_t r0, uint32_t r1, uint64_t n_bases_total, uint64_t *max_len_out) {
+__global__ __launch_bounds__(256) void widen_offsets_kernel(const uint32_t *__restrict__ in32, uint64_t *__restrict__ out64, uint32_t n) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out64[i] = in32[i];
+}
+
+// off32_out (may be null): the chunk's offsets [r0, r1] narrowed to u32, written to off32_out[r0 .. r1]
+int validate_chunk(const HostInput &in, uint32_t r0, uint32_t r1, uint64_t n_bases_total, uint64_t *max_len_out,
+                   uint32_t *off32_out = nullptr) {
     // One pass over the chunk's offsets (and unit ids) on the host threads: at 10 M reads per batch the plain loop cost the
     // submitting thread 4-5 ms of a 12 ms call, next to the pack it also waits for when the bases are pageable.
     const uint64_t *off = in.offsets;
@@ -1378,6 +1391,10 @@ int validate_chunk(const HostInput &in, uint32_t r0, uint32_t r1, uint64_t n_bas
             const uint64_t lo = off[r], hi = off[r + 1];
             e |= (uint32_t)(hi < lo) | (uint32_t)(hi > n_bases_total);
             m = std::max(m, hi - lo);
+        }
+        if (off32_out) {
+            for (uint32_t r = a; r < b; ++r) off32_out[r] = (uint32_t)off[r];
+            if (b == r1) off32_out[r1] = (uint32_t)off[r1]; // (every slice that ends at r1 writes the same value)
         }
         if (uid)
             for (uint32_t r = a + 1; r <= b && r < n_reads; ++r) e |= (uid[r] != uid[r - 1] && uid[r] != uid[r - 1] + 1) ? 2u : 0u;
@@ -1411,6 +1428,12 @@ int chunk_events(dcn_slot &sl, size_t n) {
 int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d, bool n_known = true, bool is_last = false) {
     const dcn_chunk &ch = sl.chunks[ci];
     if (wait_h2d) DCN_HIP(hipStreamWaitEvent(c->stream, sl.ev_h2d[ci], 0));
+    if (sl.off32) {
+        const uint32_t n = ch.r1 - ch.r0 + 1;
+        hipLaunchKernelGGL(widen_offsets_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                           sl.d_off32 + ch.r0, sl.d_offsets + ch.r0, n);
+        DCN_HIP(hipGetLastError());
+    }
     BatchView v;
     v.d_ascii = sl.device_pack ? sl.d_ascii : nullptr;
     v.d_packed = sl.d_packed;
@@ -1527,6 +1550,9 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     if (hits && !sl.hits_direct) DCN_TRY(ensure_pinned(&sl.h_hits, c->max_reads));
     if (total && !sl.total_direct) DCN_TRY(ensure_pinned(&sl.h_total, c->max_reads));
     const int off_pinned = is_pinned_host(in.offsets) ? 1 : 0, uid_pinned = is_pinned_host(in.unit_id) ? 1 : 0;
+    static const bool no_off32 = getenv("DCN_NO_OFF32") != nullptr; // (A/B)
+    sl.off32 = n_reads > 0 && n_bases < (1ull << 32) && !no_off32;
+    if (sl.off32) DCN_TRY(ensure_pinned(&sl.h_off32, c->max_reads + 1));
     const int pk_pinned = in.packed ? ((is_pinned_host(in.packed) && is_pinned_host(in.invmask)) ? 1 : 0) : 0;
 
     // With another batch already in flight the kernels of this batch's last chunk are covered by the next batch's
@@ -1550,7 +1576,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         DCN_HIP(hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream));
         bool saw_newline = false;
         int rc = DCN_OK;
-        if (n_reads && off_pinned) rc = staged_h2d(c, sl.d_offsets, in.offsets, (uint64_t)(n_reads + 1) * sizeof(uint64_t), 1);
+        if (n_reads && off_pinned && !sl.off32) rc = staged_h2d(c, sl.d_offsets, in.offsets, (uint64_t)(n_reads + 1) * sizeof(uint64_t), 1);
         if (rc == DCN_OK && n_reads && in.unit_id && uid_pinned)
             rc = staged_h2d(c, sl.d_unit_id, in.unit_id, (uint64_t)n_reads * sizeof(uint32_t), 1);
         uint32_t r0 = 0, u0 = 0;
@@ -1593,9 +1619,10 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                                 // behind its one piece, copied by the threads that pack it: no ring slot, no job and no
                                 // copy by the submitting thread of their own (3.5 MB per 64 Mbp chunk of 150 bp reads:
                                 // 3.7 ms of a 10 M-read call)
-                                const uint64_t n_off = (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t);
+                                const uint64_t n_off = sl.off32 ? 0 : (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t); // (u32 offsets go by themselves, below)
                                 const uint64_t n_uid = (in.unit_id && !uid_pinned) ? (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t) : 0;
-                                const bool ride = !off_pinned && !no_ride && g1 - g0 <= per_piece && 12 * (g1 - g0) + 16 + n_off + n_uid <= c->stage_bytes;
+                                const bool ride = (!off_pinned || sl.off32) && (n_off || n_uid) && !no_ride && g1 - g0 <= per_piece &&
+                                                  12 * (g1 - g0) + 16 + n_off + n_uid <= c->stage_bytes;
                                 for (uint64_t g = g0; g < g1; g += per_piece) {
                                     const uint64_t m = std::min<uint64_t>(per_piece, g1 - g);
                                     const int which = c->stage_next;
@@ -1609,7 +1636,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                                     HostPool::get().run([&](int i, int nt) {
                                         if (ride) {
                                             const uint64_t o0 = n_off * i / nt, o1 = n_off * (i + 1) / nt, q0 = n_uid * i / nt, q1 = n_uid * (i + 1) / nt;
-                                            memcpy(ho + o0, (const uint8_t *)(in.offsets + ch.r0) + o0, o1 - o0);
+                                            if (n_off) memcpy(ho + o0, (const uint8_t *)(in.offsets + ch.r0) + o0, o1 - o0);
                                             if (n_uid) memcpy(hu + q0, (const uint8_t *)(in.unit_id + ch.r0) + q0, q1 - q0);
                                         }
                                         const uint64_t per = (m + nt - 1) / nt, lo = std::min<uint64_t>(m, per * i),
@@ -1625,7 +1652,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                                     DCN_HIP(hipMemcpyAsync(dp + 2 * (g - g0), hp, m * 8, hipMemcpyHostToDevice, c->copy_stream));
                                     DCN_HIP(hipMemcpyAsync(dm + (g - g0), hm, m * 4, hipMemcpyHostToDevice, c->copy_stream));
                                     if (ride) {
-                                        DCN_HIP(hipMemcpyAsync(sl.d_offsets + ch.r0, ho, n_off, hipMemcpyHostToDevice, c->copy_stream));
+                                        if (n_off) DCN_HIP(hipMemcpyAsync(sl.d_offsets + ch.r0, ho, n_off, hipMemcpyHostToDevice, c->copy_stream));
                                         if (n_uid) DCN_HIP(hipMemcpyAsync(sl.d_unit_id + ch.r0, hu, n_uid, hipMemcpyHostToDevice, c->copy_stream));
                                         rode = true;
                                     }
@@ -1640,7 +1667,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                 // page-locked offsets / unit ids went over in one copy each before the first chunk (two runtime calls
                 // less per chunk); pageable ones are staged chunk by chunk
                 auto to = std::chrono::steady_clock::now();
-                if (!off_pinned && !rode)
+                if (!off_pinned && !rode && !sl.off32)
                     DCN_TRY(staged_h2d(c, sl.d_offsets + ch.r0, in.offsets + ch.r0, (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint64_t), 0));
                 if (in.unit_id && !uid_pinned && !rode)
                     DCN_TRY(staged_h2d(c, sl.d_unit_id + ch.r0, in.unit_id + ch.r0, (uint64_t)(ch.r1 - ch.r0) * sizeof(uint32_t), 0));
@@ -1651,9 +1678,17 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
             if (saw_newline) break; // this attempt is abandoned
             // validated while the copies above are in flight; the kernels are only queued in the second pass
             auto tv = std::chrono::steady_clock::now();
-            rc = validate_chunk(in, ch.r0, ch.r1, n_bases, &ch.max_len);
+            rc = validate_chunk(in, ch.r0, ch.r1, n_bases, &ch.max_len, sl.off32 ? sl.h_off32 : nullptr);
             lap(4, tv);
             if (rc != DCN_OK) break;
+            if (sl.off32) { // narrowed by the check's own pass over them, into the slot's page-locked copy
+                hipError_t he2 = hipMemcpyAsync(sl.d_off32 + ch.r0, sl.h_off32 + ch.r0, (uint64_t)(ch.r1 - ch.r0 + 1) * sizeof(uint32_t),
+                                                hipMemcpyHostToDevice, c->copy_stream);
+                if (he2 != hipSuccess) {
+                    rc = dcn_fail(DCN_ERR_HIP, std::string("hipMemcpyAsync (offsets): ") + hipGetErrorString(he2));
+                    break;
+                }
+            }
             if (ch.u1 < ch.u0 || (uint64_t)ch.u1 - ch.u0 > (uint64_t)ch.r1 - ch.r0) {
                 rc = dcn_fail(DCN_ERR_ARG, "unit_id must stay equal or grow by one");
                 break;

@@ -699,8 +699,10 @@ def run_host_path(index, batches, params, oidx, cores, calls=6, reads_per_call=1
     except OSError:
         wide_pack = False
     off_b = 4 if (n_bases < 2**32 and not os.environ.get("DCN_NO_OFF32")) else 8  # offsets go as u32 when they fit (api.hip)
-    link_bytes = {"pageable": 0.375 * n_bases + off_b * n_reads, "pinned": (0.375 if wide_pack else 1.0) * n_bases + off_b * n_reads,
-                  "packed": 0.375 * n_bases + off_b * n_reads}
+    # the invalid-base mask (0.125 B/bp whole) goes as its non-zero words only: nothing for these N-free reads
+    pk_b = 0.25 if not os.environ.get("DCN_NO_SPARSE_MASK") else 0.375
+    link_bytes = {"pageable": pk_b * n_bases + off_b * n_reads, "pinned": (pk_b if wide_pack else 1.0) * n_bases + off_b * n_reads,
+                  "packed": pk_b * n_bases + off_b * n_reads}
     out["pinned_ascii_transport"] = "packed by the host threads (AVX-512)" if wide_pack else "sent as it is, packed on the device"
 
     def wait(tk):

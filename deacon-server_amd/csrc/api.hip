@@ -319,10 +319,18 @@ extern "C" void dcn_index_destroy(dcn_index *index) {
 // context
 // ----------------------------------------------------------------------------------------------------
 // One pipeline step of a host batch: reads [r0, r1) = units [u0, u1) = bases [b0, b1) of the batch stream.
+// groups [g0, g1) of the invalid-base mask that crossed the link as their non-zero words only: n (group, word) pairs at
+// pairs_off of the slot's pair buffer; the range is cleared and the pairs scattered in front of the chunk's kernels
+struct dcn_mask_range {
+    uint64_t g0 = 0, g1 = 0, pairs_off = 0;
+    uint32_t n = 0;
+};
+
 struct dcn_chunk {
     uint32_t r0 = 0, r1 = 0, u0 = 0, u1 = 0;
     uint64_t b0 = 0, b1 = 0;
     uint64_t max_len = 0; // longest read of the chunk
+    std::vector<dcn_mask_range> mask_ranges;
 };
 
 // One host batch in flight (dcn_filter_batch_submit .. dcn_filter_batch_wait).  Everything a later batch's copies
@@ -340,6 +348,11 @@ struct dcn_slot {
     // and are widened into d_offsets by a kernel in front of each chunk's own kernels
     uint32_t *d_off32 = nullptr, *h_off32 = nullptr;
     bool off32 = false;
+    // The invalid-base mask of a packed stream is a third of its bytes and almost all zero (a word per 32 bases, non-zero
+    // only where a base is not ACGT): its non-zero words cross the link as (group, word) pairs, the rest is a memset on the
+    // device.  A chunk whose pairs do not fit (one group in 16 non-zero, over the batch) goes whole.
+    uint2 *d_mask_pairs = nullptr, *h_mask_pairs = nullptr;
+    uint64_t mask_pairs_cap = 0, mask_pairs_used = 0;
     uint32_t *d_unit_id = nullptr;
     uint8_t *d_keep = nullptr;
     uint32_t *d_hits = nullptr, *d_total = nullptr;
@@ -467,7 +480,8 @@ void free_slot_buffers(dcn_slot &sl) {
     }
     if (sl.d_report) hipFree(sl.d_report);
     if (sl.d_off32) hipFree(sl.d_off32);
-    void *host[] = {sl.h_keep, sl.h_hits, sl.h_total, sl.h_report, sl.h_off32};
+    if (sl.d_mask_pairs) hipFree(sl.d_mask_pairs);
+    void *host[] = {sl.h_keep, sl.h_hits, sl.h_total, sl.h_report, sl.h_off32, sl.h_mask_pairs};
     for (void *p : host)
         if (p) hipHostFree(p);
     if (sl.done) hipEventDestroy(sl.done);
@@ -1326,6 +1340,9 @@ int alloc_slot_impl(dcn_ctx *c, int si) {
     }
     DCN_TRY(dev_alloc(&sl.d_report, 1, "slot report"));
     DCN_TRY(dev_alloc(&sl.d_off32, MR + 1, "slot offsets (u32)"));
+    sl.mask_pairs_cap = std::max<uint64_t>(4096, mask_words(c->max_bases) / 16);
+    if (const char *e = getenv("DCN_SPARSE_MASK_CAP")) sl.mask_pairs_cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10)); // (tests: force the whole-mask path)
+    DCN_TRY(dev_alloc(&sl.d_mask_pairs, sl.mask_pairs_cap, "slot mask pairs"));
     DCN_HIP(hipHostMalloc((void **)&sl.h_report, sizeof(dcn_batch_report), hipHostMallocDefault));
     DCN_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     sl.allocated = true;
@@ -1369,6 +1386,44 @@ uint32_t find_cut(const dcn_ctx *c, const HostInput &in, uint32_t r0, uint64_t c
 __global__ __launch_bounds__(256) void widen_offsets_kernel(const uint32_t *__restrict__ in32, uint64_t *__restrict__ out64, uint32_t n) {
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out64[i] = in32[i];
+}
+
+__global__ __launch_bounds__(256) void scatter_mask_kernel(const uint2 *__restrict__ pairs, uint32_t n, uint32_t *__restrict__ invmask) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) invmask[pairs[i].x] = pairs[i].y;
+}
+
+// The non-zero words of mask[0, m) (group g_base + i of the stream) appended to the slot's page-locked pair buffer, found by
+// the pool.  false: sparse form off, or no room left -- the caller sends the words whole.
+bool sparse_mask_pairs(dcn_slot &sl, const uint32_t *mask, uint64_t g_base, uint64_t m, dcn_mask_range *out) {
+    if (getenv("DCN_NO_SPARSE_MASK") || g_base + m > 0xFFFFFFFFull) return false; // (read per chunk: tests switch it)
+    if (ensure_pinned(&sl.h_mask_pairs, sl.mask_pairs_cap) != DCN_OK) return false;
+    std::vector<std::vector<uint2>> found((size_t)std::max(1, HostPool::get().width()));
+    HostPool::get().run([&](int i, int nt) {
+        const uint64_t per = (m + nt - 1) / nt, lo = std::min<uint64_t>(m, per * i), hi = std::min<uint64_t>(m, lo + per);
+        std::vector<uint2> &v = found[(size_t)i];
+        uint64_t j = lo;
+        for (; j + 8 <= hi; j += 8) { // (the OR of eight words first: zero nearly always)
+            const uint32_t *q = mask + j;
+            if ((q[0] | q[1] | q[2] | q[3] | q[4] | q[5] | q[6] | q[7]) == 0) continue;
+            for (int t = 0; t < 8; ++t)
+                if (q[t]) v.push_back(make_uint2((uint32_t)(g_base + j + t), q[t]));
+        }
+        for (; j < hi; ++j)
+            if (mask[j]) v.push_back(make_uint2((uint32_t)(g_base + j), mask[j]));
+    }, m < (1u << 16));
+    uint64_t total = 0;
+    for (const auto &v : found) total += v.size();
+    if (sl.mask_pairs_used + total > sl.mask_pairs_cap) return false;
+    out->g0 = g_base;
+    out->g1 = g_base + m;
+    out->pairs_off = sl.mask_pairs_used;
+    out->n = (uint32_t)total;
+    for (const auto &v : found) {
+        if (!v.empty()) memcpy(sl.h_mask_pairs + sl.mask_pairs_used, v.data(), v.size() * sizeof(uint2));
+        sl.mask_pairs_used += v.size();
+    }
+    return true;
 }
 
 // off32_out (may be null): the chunk's offsets [r0, r1] narrowed to u32, written to off32_out[r0 .. r1]
@@ -1433,6 +1488,14 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d, bool n_kno
         hipLaunchKernelGGL(widen_offsets_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, c->stream,
                            sl.d_off32 + ch.r0, sl.d_offsets + ch.r0, n);
         DCN_HIP(hipGetLastError());
+    }
+    for (const dcn_mask_range &mr : ch.mask_ranges) { // mask words that crossed the link as their non-zero ones only
+        DCN_HIP(hipMemsetAsync(sl.d_invmask + DCN_FRONT_PAD + mr.g0, 0, (mr.g1 - mr.g0) * sizeof(uint32_t), c->stream));
+        if (mr.n) {
+            hipLaunchKernelGGL(scatter_mask_kernel, dim3(std::min<uint32_t>((mr.n + 255) / 256, 1024)), dim3(256), 0, c->stream,
+                               sl.d_mask_pairs + mr.pairs_off, mr.n, sl.d_invmask + DCN_FRONT_PAD);
+            DCN_HIP(hipGetLastError());
+        }
     }
     BatchView v;
     v.d_ascii = sl.device_pack ? sl.d_ascii : nullptr;
@@ -1573,6 +1636,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     for (int attempt = 0;; ++attempt) {
         sl.device_pack = tr == Transport::AsciiDirect || tr == Transport::AsciiStaged;
         sl.chunks.clear();
+        sl.mask_pairs_used = 0;
         DCN_HIP(hipMemsetAsync(sl.d_report, 0, sizeof(dcn_batch_report), c->stream));
         bool saw_newline = false;
         int rc = DCN_OK;
@@ -1610,7 +1674,15 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                             uint32_t *dp = sl.d_packed + DCN_FRONT_PAD + 2 * g0, *dm = sl.d_invmask + DCN_FRONT_PAD + g0;
                             if (tr == Transport::Packed) {
                                 DCN_TRY(staged_h2d(c, dp, in.packed + 2 * g0, (g1 - g0) * 8, pk_pinned));
-                                DCN_TRY(staged_h2d(c, dm, in.invmask + g0, (g1 - g0) * 4, pk_pinned));
+                                dcn_mask_range mr;
+                                if (sparse_mask_pairs(sl, in.invmask + g0, g0, g1 - g0, &mr)) {
+                                    if (mr.n)
+                                        DCN_HIP(hipMemcpyAsync(sl.d_mask_pairs + mr.pairs_off, sl.h_mask_pairs + mr.pairs_off, (uint64_t)mr.n * sizeof(uint2),
+                                                               hipMemcpyHostToDevice, c->copy_stream));
+                                    ch.mask_ranges.push_back(mr);
+                                } else {
+                                    DCN_TRY(staged_h2d(c, dm, in.invmask + g0, (g1 - g0) * 4, pk_pinned));
+                                }
                             } else {
                                 // pieces of whole groups: 8 bytes of stream + 4 of mask per group, side by side in a
                                 // staging buffer, packed there by the host threads
@@ -1650,7 +1722,15 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                                     lap(1, tl);
                                     saw_newline = saw_newline || nl.load();
                                     DCN_HIP(hipMemcpyAsync(dp + 2 * (g - g0), hp, m * 8, hipMemcpyHostToDevice, c->copy_stream));
-                                    DCN_HIP(hipMemcpyAsync(dm + (g - g0), hm, m * 4, hipMemcpyHostToDevice, c->copy_stream));
+                                    dcn_mask_range mr;
+                                    if (sparse_mask_pairs(sl, hm, g, m, &mr)) {
+                                        if (mr.n)
+                                            DCN_HIP(hipMemcpyAsync(sl.d_mask_pairs + mr.pairs_off, sl.h_mask_pairs + mr.pairs_off, (uint64_t)mr.n * sizeof(uint2),
+                                                                   hipMemcpyHostToDevice, c->copy_stream));
+                                        ch.mask_ranges.push_back(mr);
+                                    } else {
+                                        DCN_HIP(hipMemcpyAsync(dm + (g - g0), hm, m * 4, hipMemcpyHostToDevice, c->copy_stream));
+                                    }
                                     if (ride) {
                                         if (n_off) DCN_HIP(hipMemcpyAsync(sl.d_offsets + ch.r0, ho, n_off, hipMemcpyHostToDevice, c->copy_stream));
                                         if (n_uid) DCN_HIP(hipMemcpyAsync(sl.d_unit_id + ch.r0, hu, n_uid, hipMemcpyHostToDevice, c->copy_stream));

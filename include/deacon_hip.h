@@ -215,7 +215,7 @@ int dcn_filter_batch_wait(dcn_ctx *ctx, uint64_t ticket);
  * Both arrays must be allocated in whole 32-base groups: 2 * ceil(n_bases/32) and ceil(n_bases/32) words
  * (dcn_pack_ascii fills them).  Reads must not end in a newline byte, 0x0A (src/filter_common.rs:229 strips one from
  * the ASCII; a packed stream cannot show it: dcn_pack_ascii reports whether it met one).  The pack kernel is skipped;
- * 0.375 bytes per base cross the link. */
+ * 0.25 bytes per base cross the link, plus the non-zero words of invmask (the rest of it is a memset on the device). */
 int dcn_filter_batch_packed(dcn_ctx *ctx, const uint32_t *packed, const uint32_t *invmask, const uint64_t *offsets,
                             const uint32_t *unit_id, uint32_t n_reads, const dcn_params *params, uint8_t *keep,
                             uint32_t *hits, uint32_t *total);

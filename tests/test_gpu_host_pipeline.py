@@ -82,6 +82,30 @@ def test_chunked_batch_matches_oracle(oracle, dcn, genome, index_pair, monkeypat
     proc.close()
 
 
+@pytest.mark.parametrize("mode", ["tiny-cap", "off"])
+def test_invalid_mask_sparse_and_whole(oracle, dcn, genome, index_pair, monkeypatch, mode):
+    """the invalid-base mask of a packed stream crosses the link as its non-zero words only; a batch whose words do not fit
+    the pair buffer (here: room for 40 pairs, so the first chunks go sparse and the rest whole) and the form switched off give
+    the same results, for the library's own pack and for a caller-packed batch, N-rich reads included"""
+    small_chunks(monkeypatch, 30_000)
+    if mode == "tiny-cap":
+        monkeypatch.setenv("DCN_SPARSE_MASK_CAP", "40")
+    else:
+        monkeypatch.setenv("DCN_NO_SPARSE_MASK", "1")
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(171)
+    reads = mixed_reads(rng, genome, 1500, 5)
+    reads += [bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), 400, p=[0.2, 0.2, 0.2, 0.2, 0.2])) for _ in range(40)]
+    b, o = oracle.concat_reads(reads)
+    proc = dcn.FilterProcessor(gidx, max_batch_bases=len(b) + 64, max_batch_reads=len(reads))
+    want = oracle_batch(oracle, oidx, proc, b, o, None)
+    assert_same(proc.filter_batch(b, o), want)
+    packed, mask = dcn.pack_ascii(b)
+    assert int(np.count_nonzero(mask)) > 40
+    assert_same(proc.filter_batch_packed(packed, mask, o), want)
+    proc.close()
+
+
 @pytest.mark.parametrize("host_pack", [True, False])
 def test_small_staging_ring_many_pieces_per_chunk(oracle, dcn, genome, index_pair, monkeypatch, host_pack):
     """pageable input through 8 KB staging buffers: every chunk's payload (host-packed stream + mask, or ASCII with

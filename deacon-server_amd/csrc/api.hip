@@ -1646,7 +1646,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         uint32_t r0 = 0, u0 = 0;
         uint64_t groups_done = 0; // 32-base groups of the stream already sent (HostPacked / Packed)
         static const bool no_interleave = getenv("DCN_NO_INTERLEAVE") != nullptr, no_ride = getenv("DCN_NO_RIDE") != nullptr; // (A/B)
-        const bool interleave = (tr == Transport::HostPacked || tr == Transport::AsciiStaged) && !no_interleave;
+        const bool interleave = !no_interleave;
         while (r0 < n_reads && rc == DCN_OK) {
             dcn_chunk ch;
             ch.r0 = r0;
@@ -1788,11 +1788,11 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
                 lap(5, tk);
             }
         }
-        // second pass: the kernels.  Every copy is already queued, so the link never waits for the host to get round
-        // to the next chunk (a chunk's ~15 runtime calls cost about as much host time as its copy takes on the link).
-        // Where the HOST is the slower side (it packs or stages pageable bases chunk by chunk) the kernels of a chunk are
-        // queued as soon as the next chunk's copies are, one chunk behind, instead: they then run under the packing of
-        // the chunks that follow, not after it (a blocking 10 M-read call of pageable bases: 19.3 -> 15 ms).
+        // The kernels of a chunk are queued as soon as the next chunk's copies are, one chunk behind: they then run under
+        // the host's work on the chunks that follow (packing pageable bases: a blocking 10 M-read call 19.3 -> 15 ms; scanning a
+        // caller's mask for its non-zero words: 10.5 -> 8.8 ms), not after it.  (Until late in round 3 all copies were queued
+        // first and all kernels after them -- right while a chunk's runtime calls cost the host as much as its copy took on
+        // the link; a chunk's copy is three times that now.  DCN_NO_INTERLEAVE=1 brings the two passes back.)
         auto tk = std::chrono::steady_clock::now();
         if (interleave) {
             if (rc == DCN_OK && !saw_newline && !sl.chunks.empty()) rc = enqueue_chunk(c, sl, sl.chunks.size() - 1, true, false, true);

@@ -1795,7 +1795,17 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
         // the link; a chunk's copy is three times that now.  DCN_NO_INTERLEAVE=1 brings the two passes back.)
         auto tk = std::chrono::steady_clock::now();
         if (interleave) {
-            if (rc == DCN_OK && !saw_newline && !sl.chunks.empty()) rc = enqueue_chunk(c, sl, sl.chunks.size() - 1, true, false, true);
+            if (rc == DCN_OK && !saw_newline && !sl.chunks.empty()) {
+                const size_t n_ch = sl.chunks.size();
+                if (!sl.counts && n_ch >= 4) { // the decisions of every chunk but the last go back while the last one's kernels run
+                    hipError_t he = hipEventRecord(sl.ev_comp[n_ch - 2], c->stream);
+                    if (he == hipSuccess) he = hipStreamWaitEvent(c->d2h_stream, sl.ev_comp[n_ch - 2], 0);
+                    if (he == hipSuccess)
+                        he = hipMemcpyAsync(sl.keep_direct ? sl.u_keep : sl.h_keep, sl.d_keep, sl.chunks[n_ch - 2].u1, hipMemcpyDeviceToHost, c->d2h_stream);
+                    if (he != hipSuccess) rc = dcn_fail(DCN_ERR_HIP, std::string("early result copy: ") + hipGetErrorString(he));
+                }
+                if (rc == DCN_OK) rc = enqueue_chunk(c, sl, n_ch - 1, true); // (all chunks known now: it copies its own decisions only)
+            }
         } else {
             for (size_t ci = 0; rc == DCN_OK && !saw_newline && ci < sl.chunks.size(); ++ci) rc = enqueue_chunk(c, sl, ci, true);
         }

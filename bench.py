@@ -2,7 +2,9 @@
 """Headline benchmark: Mbp/s filtered (k=31, w=15) against a panhuman-1-sized index on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a launcher: this file starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...` of itself
+   as a CHILD process -- before anything here has touched the GPU -- relays the child's output and exits with its code;
+   under torch.distributed.run (RANK / WORLD_SIZE set) it is one rank of that job, as the task contract launches it.)
 
 One "step" = one pass of the hot path (pack -> plan -> scan/hash/probe/distinct -> finish) over one batch of
 synthetic 150 bp reads that is already resident in HBM as ASCII + offsets (BASELINE.json configs[1]).  Three distinct
@@ -12,26 +14,80 @@ plus pseudo-random keys mix64(1..n); half of the reads are drawn from the host g
 half are random.  Weak scaling: every rank holds a full index replica and filters its own batches; the only
 collective is the all-reduce of the six summary counters (RCCL) at the end of the timed region.
 
-Prints ONE JSON line on rank 0 (see the task contract): value = whole-job Mbp/s of that workload, plus
+Output.  The LAST stdout line (rank 0) is the contract's JSON, kept small (compact_line(): < 4 KB, never above 8 KB):
+value = whole-job Mbp/s of that workload, plus
   roofline      dominant kernel (scan): algorithmic HBM bytes / HIP-event time on the kernel's own stream; `traffic` = HBM bytes
                 per launch from PMC counters, measured after the timed region by child runs of this file under rocprofv3 --pmc
   cpu_baseline  the CPU oracle (oracle/, "port") on a bounded sample of the same reads, all host cores
-and, at N = 1 (after the timed region; none of it enters `value`):
-  workloads.{long,paired,union950m,host1g,host95}   BASELINE configs[2], [3], [4]-sized table, and a >= 1 Gbp host genome
-  host_path.{pageable,pinned,packed,...}     the PCIe-inclusive rate of dcn_filter_batch* from host memory
-each with its own roofline block and a check of the GPU's decisions against the CPU oracle on a bounded sample.
+and one scalar per extra leg measured at N = 1 after the timed region (none of it enters `value`):
+  legs.{long,paired,union950m,...}           BASELINE configs[2], [3], [4]-sized table: Mbp/s + the oracle check
+  host_path.{pageable,pinned,packed}         the PCIe-inclusive rate of dcn_filter_batch* from host memory
+  cli.{search50,deplete95,paired}            `deacon-hip filter` file to file
+Everything else that is measured (per-stage times, repetitions, counters, samples checked) goes to bench_detail.json next
+to this file (--detail PATH) and, as one line, to stderr.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch  # first: libdeacon_hip.so must bind to the HIP runtime torch already loaded
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _flag_value(argv, name, default):
+    """value of `--name V` / `--name=V` in argv (the launcher parent reads --gpus without building the whole parser)"""
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+def self_launch_if_needed(argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N-rank job as a child process, relay
+    its stdout (rank 0's final JSON line is the last thing it prints) and return its exit code.  Runs before torch or the
+    library is imported, so this process has made no GPU call; it never replaces itself (no exec), it waits for the child.
+    The reference's counterpart is one command starting all of its workers (src/local_filter.rs:696-709)."""
+    try:
+        n = int(_flag_value(argv, "--gpus", "1"))
+    except ValueError:
+        return None
+    if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool: RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", "1")             # (torchrun sets it anyway, and says so on stderr)
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait()
+    except BaseException:
+        child.kill()
+        child.wait()
+        raise
+
+
+if __name__ == "__main__":
+    _rc = self_launch_if_needed(sys.argv[1:])
+    if _rc is not None:
+        sys.exit(_rc)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  first: libdeacon_hip.so must bind to the HIP runtime torch already loaded
+import torch.distributed as dist  # noqa: E402
+
 sys.path.insert(0, ROOT)
 import deacon_server_amd as dcn  # noqa: E402
 
@@ -44,6 +100,9 @@ PCIE_PEAK_GBS = 64.0         # PCIe Gen5 x16, one direction
 SCATTER_CEILING = 46e9  # random 16-byte reads/s of a 2^31-slot table on MI355X, measured (profiles/r01_probe_patterns_17GB.txt)
 ROTATE = 3
 T0 = time.time()
+# Extras that follow the headline at N = 1 by default (the whole run stays near a minute), and every one there is
+DEFAULT_EXTRAS = "long,paired,host_path,pmc,union950m,cli"
+ALL_EXTRAS = "long,paired,host_path,cli,pmc,host1g,host95,union950m,union950m_paired,pmc_legs"
 
 
 def log(*a):
@@ -459,8 +518,9 @@ def live_traffic(workload, reads, index_keys, host_genome):
     try:
         for name, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE", "TCC_HIT", "TCC_MISS"])):
             od = os.path.join(d, name)
-            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", od, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--workload", workload, "--reads", str(reads),
+            cmd = [exe, "--pmc", *counters, "--kernel-include-regex", "scan_kernel", "--output-format", "csv", "-d", od, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--pmc-child", "--workload", workload, "--reads", str(reads),
                    "--index-keys", str(index_keys), "--host-genome", str(host_genome)]
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
@@ -565,7 +625,7 @@ def check_against_oracle(oidx, batch, params, max_bases, threads, keep_dev=None)
     return ok, f"first {len(off) - 1} reads ({int(off[-1]) / 1e6:.1f} Mbp) of batch 0"
 
 
-def cpu_baseline(oidx, cores, batch, params, seconds_target=12.0, tuned=False, port_result=None):
+def cpu_baseline(oidx, cores, batch, params, seconds_target=10.0, tuned=False, port_result=None):
     """Time the CPU oracle (all host cores) on a bounded sample of the headline reads and check the GPU's decisions
     on that sample against it.  tuned: the "port-tuned" form of the same arithmetic (oracle/deacon_oracle.c,
     dor_filter_batch_tuned_mt: one workspace per thread, two-stack window minima, epoch-tagged seen-set, rolling
@@ -783,6 +843,208 @@ def run_host_path(index, batches, params, oidx, cores, calls=6, reads_per_call=1
     return out
 
 
+# ---- what is printed -------------------------------------------------------------------------------------------------
+LINE_TARGET, LINE_CAP = 4096, 8192
+
+
+def _r(x, sig=6):
+    """floats to `sig` significant digits (what a reader of the line needs; the detail file keeps them whole)"""
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None  # the line is dumped with allow_nan=False: a figure that could not be computed is null
+        return float(f"{x:.{sig}g}")
+    return x
+
+
+def _pick(d, keys):
+    return {k_: (_short(d[k_], 80) if isinstance(d[k_], str) else _r(d[k_])) for k_ in keys
+            if isinstance(d, dict) and k_ in d and not isinstance(d[k_], (dict, list))}
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + "..."
+
+
+def compact_line(out):
+    """The contract's JSON line from the full result `out`: the contract's keys whole, the roofline and cpu_baseline
+    objects with the figures a check recomputes, and per extra leg its rate and whether the oracle agreed.  Free text is
+    cut to a bounded length, so no leg, sample description or error message can make the line outgrow LINE_CAP."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data"))
+    for k_, n_ in (("metric", 120), ("unit", 16), ("scaling", 8), ("dtype", 16), ("data", 60)):
+        if isinstance(c.get(k_), str):
+            c[k_] = _short(c[k_], n_)
+    c["parity"] = _short(out.get("parity", ""), 160)
+    cfg = out.get("config") or {}
+    c["config"] = _pick(cfg, ("index_keys", "reads_per_batch_per_gpu", "bases_per_batch_per_gpu", "distinct_batches_rotated", "k", "w",
+                              "host_fraction", "parallelism"))
+    c["config"]["workload"] = _short(cfg.get("workload", ""), 200)
+    rf = out.get("roofline") or {}
+    c["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                               "minimizers_per_launch", "scattered_probes_per_s", "probe_ceiling_replay_per_s", "frac_of_probe_ceiling",
+                               "traffic_frac_of_peak"))
+    c["roofline"]["kernel"] = _short(rf.get("kernel", ""), 80)
+    c["roofline"].setdefault("traffic", None)
+    if rf.get("traffic_source"):
+        c["roofline"]["traffic_source"] = "live rocprofv3 --pmc child runs" if str(rf["traffic_source"]).startswith("live") else _short(rf["traffic_source"], 60)
+    for key in ("cpu_baseline", "cpu_baseline_tuned"):
+        cb = out.get(key)
+        if cb:
+            c[key] = _pick(cb, ("value", "unit", "cores", "kind", "decisions_match_gpu", "equals_port"))
+            if key == "cpu_baseline":
+                c[key]["sample"] = _short(cb.get("sample", ""), 200)
+        elif key == "cpu_baseline":
+            c[key] = None
+    if out.get("cpu_baseline_error"):
+        c["cpu_baseline_error"] = _short(out["cpu_baseline_error"], 120)
+    if "decisions_match_gpu" in out:
+        c["decisions_match_gpu"] = out["decisions_match_gpu"]
+    do = out.get("decisions_only")
+    if do:
+        c["decisions_only"] = _pick(do, ("value", "ms_per_step", "decisions_identical_to_counting_mode"))
+    col = out.get("collective")
+    if col:
+        c["collective"] = _pick(col, ("backend", "world_size", "total_bp_all_reduced", "total_bp_expected", "total_bp_matches"))
+    oks = []
+
+    def leg(d):
+        if "error" in d:
+            oks.append(False)
+            return {"error": _short(d["error"], 100)}
+        e = {"value": _r(d.get("value"))}
+        for k_ in ("decisions_match_gpu", "decisions_match"):
+            if k_ in d:
+                e["decisions_match"] = bool(d[k_])
+                oks.append(bool(d[k_]))
+        return e
+
+    if out.get("workloads"):
+        c["legs"] = {}
+        for name, d in out["workloads"].items():
+            e = leg(d)
+            if "error" not in e:
+                if isinstance(d.get("decisions_only"), dict):
+                    e["decisions_only"] = _r(d["decisions_only"].get("value"))
+                r2 = d.get("roofline") or {}
+                e.update(_pick(r2, ("frac", "avg_launch_ms", "traffic")))
+            c["legs"][_short(name, 24)] = e
+    hp = out.get("host_path")
+    if hp:
+        c["host_path"] = {"unit": "Mbp/s, PCIe included; never `value`"} if "error" not in hp else {"error": _short(hp["error"], 100)}
+        c["host_path"].update(_pick(hp, ("reads_per_call",)))
+        for kind in ("pageable", "pinned", "packed"):
+            if isinstance(hp.get(kind), dict):
+                e = leg(hp[kind])
+                tf = hp[kind].get("two_in_flight") or {}
+                e["two_in_flight"] = _r(tf.get("value"))
+                e["link_GBps"] = _r(hp[kind].get("link_GBps"))
+                if "sum_over_ranks_Mbp_per_s" in tf:
+                    e["node_sum_two_in_flight"] = _r(tf["sum_over_ranks_Mbp_per_s"])
+                c["host_path"][kind] = e
+    cli = out.get("cli")
+    if cli:
+        c["cli"] = {"unit": "Mbp/s file to file"} if "error" not in cli else {"error": _short(cli["error"], 100)}
+        for name, d in cli.items():
+            if not isinstance(d, dict):
+                continue
+            e = {}
+            for src, dst in (("Mbp_per_s_incl_index_load", "value"), ("Mbp_per_s_filter_only", "filter_only"), ("decisions_match", "decisions_match")):
+                if src in d:
+                    e[dst] = _r(d[src])
+            if "decisions_match" in d:
+                oks.append(bool(d["decisions_match"]))
+            if e:
+                c["cli"][_short(name, 24)] = e
+    for key in ("cpu_baseline", "cpu_baseline_tuned"):
+        if out.get(key) and "decisions_match_gpu" in out[key]:
+            oks.append(bool(out[key]["decisions_match_gpu"]))
+    c["all_checks_ok"] = bool(all(oks)) if oks else None
+    c["checks"] = len(oks)
+    c["bench_wall_s"] = _r(out.get("bench_wall_s"), 4)
+    c["detail"] = out.get("detail_file")
+    return c
+
+
+def emit(out, detail_path):
+    """Write the full result to `detail_path` and (one line) to stderr, then print the compact contract line as the LAST
+    stdout line.  Strict JSON (allow_nan=False); should the compact line ever exceed LINE_CAP the optional blocks are
+    dropped, in this order, until it fits."""
+    out["detail_file"] = None
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1, default=str)
+            out["detail_file"] = os.path.basename(detail_path)
+        except OSError as ex:
+            log(f"could not write {detail_path}: {ex!r}")
+    try:
+        print("[bench detail] " + json.dumps(out, default=str), file=sys.stderr, flush=True)
+    except Exception:
+        pass
+    c = compact_line(out)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    for drop in ("cli", "host_path", "legs", "cpu_baseline_tuned", "decisions_only", "collective"):
+        if len(line) <= LINE_CAP:
+            break
+        c.pop(drop, None)
+        c["dropped_for_size"] = c.get("dropped_for_size", []) + [drop]
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    sys.stderr.flush()
+    print(line, flush=True)
+    return line
+
+
+def stub_main(args, rank, world):
+    """DCN_BENCH_STUB=1: a rehearsal of the launch, rendezvous, barriers, the counters' all-reduce, the max-over-ranks clock
+    and the printed line with NO filter engine behind it (a step adds up the lengths of a synthetic batch on the CPU).
+    For tests of the N > 1 plumbing on a machine without a GPU (tests/test_bench_line.py); its line says what it is."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=os.environ.get("DCN_BENCH_BACKEND", "gloo"))
+    cpu = torch.device("cpu")
+    n_reads = min(args.reads, 100_000)
+    lens = np.full(n_reads, READ_LEN, np.int64)
+    local = {n: 0 for n in dcn._native.STAT_NAMES}
+
+    def step():
+        local["total_seqs"] += n_reads
+        local["total_bp"] += int(lens.sum())
+
+    for _ in range(args.warmup):
+        step()
+    local = {n: 0 for n in dcn._native.STAT_NAMES}
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    counters = dcn.distributed.allreduce_counters(local, device=cpu)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        expected = world * args.steps * n_reads * READ_LEN
+        out = {"metric": "STUB: launcher rehearsal, nothing is filtered (DCN_BENCH_STUB=1)", "value": counters["total_bp"] / elapsed / 1e6,
+               "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "stub", "parity": "not applicable (stub)",
+               "config": {"workload": "stub: lengths of synthetic 150 bp reads added up on the CPU", "reads_per_batch_per_gpu": n_reads,
+                          "bases_per_batch_per_gpu": n_reads * READ_LEN, "k": K, "w": W, "parallelism": f"reads sharded x{world}"},
+               "roofline": {"bound": "hbm", "kernel": "none (stub)", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+               "cpu_baseline": None,
+               "collective": {"backend": str(dist.get_backend()) if world > 1 else None, "world_size": world,
+                              "total_bp_all_reduced": int(counters["total_bp"]), "total_bp_expected": expected,
+                              "total_bp_matches": int(counters["total_bp"]) == expected},
+               "bench_wall_s": time.time() - T0}
+        emit(out, args.detail)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -800,9 +1062,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the other configs and the host-path measurements that follow the headline at N = 1")
-    ap.add_argument("--extras", default="long,paired,host_path,cli,pmc,host1g,host95,union950m",
-                    help="which of the extra measurements to run (comma separated)")
+    ap.add_argument("--extras", default=DEFAULT_EXTRAS,
+                    help="which of the extra measurements to run (comma separated); all of them: " + ALL_EXTRAS)
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="(internal) the run live_traffic() starts under rocprofv3 --pmc: the timed steps only, nothing else measured or written")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full result goes (the last stdout line is its compact form); '' = nowhere")
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_cpu_baseline, args.no_extras, args.detail = True, True, ""
 
     # torch sizes its CPU thread pool by the machine (256 hardware threads on the GPU box) while the job's CPU quota is a
     # 16th of it: one parallel CPU op would spend the quota of its 100 ms period at once and the host legs that follow
@@ -811,10 +1079,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:  # (a plain `bench.py --gpus N` has become a torch.distributed.run child above: self_launch_if_needed)
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: running as the launcher says")
         args.gpus = world
+    if os.environ.get("DCN_BENCH_STUB"):
+        return stub_main(args, rank, world)
     # rehearsal of the N > 1 path on a one-GPU box (profiles/rehearse_two_ranks.sh): every rank on GPU 0, collectives
     # on gloo (RCCL does not take two ranks on one device).  The driver's scaling run uses neither variable.
     backend = os.environ.get("DCN_BENCH_BACKEND", "nccl")
@@ -884,30 +1153,32 @@ def main():
         rf = head["roofline"]
         traffic = committed_traffic(rf, args.workload, batches[0].n_bases, int(index.n_keys), args.host_genome)
         try:
-            rf["probe_only_kernel_live_per_s"] = probe_only_rate(index, device)
-            rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
+            if not args.pmc_child:
+                rf["probe_only_kernel_live_per_s"] = probe_only_rate(index, device)
+                rf["frac_of_probe_only_kernel_live"] = rf["scattered_probes_per_s"] / rf["probe_only_kernel_live_per_s"]
         except Exception as ex:
             log(f"probe-only measurement failed: {ex!r}")
         try:
-            # ONE bound the kernel cannot exceed: the same table serving the same key stream -- batch 0's own
-            # minimizer hashes, in the kernel's order -- to a kernel that does nothing but issue the home-group reads
-            # (dcn_index_probe_ceiling: best of six launch shapes).  Beside it, the same for uniformly random groups (no
-            # reuse at all: every request an L2 miss), which is what the documented 46 G/s stands for.
-            t_c = time.time()
-            rf["probe_ceiling_random_per_s"] = index.probe_ceiling(None, 1 << 27, reps=3)
-            if args.workload == "short":
-                b0 = batches[0]
-                pc = dcn.FilterProcessor(index, max_batch_bases=b0.n_bases, max_batch_reads=b0.n_reads)
-                _, hs, _ = pc.minimizer_hashes_batch(b0.d_bases.cpu().numpy(), b0.d_offsets.cpu().numpy().astype(np.uint64))
-                pc.close()
-                d_h = torch.from_numpy(hs.view(np.int64)).to(device)
-                rf["probe_ceiling_replay_per_s"] = index.probe_ceiling(d_h.data_ptr(), d_h.numel(), reps=3)
-                rf["probe_ceiling_replay_stream"] = f"the {d_h.numel():,} valid minimizer hashes of batch 0, in read order"
-                rf["frac_of_probe_ceiling"] = rf["scattered_probes_per_s"] / rf["probe_ceiling_replay_per_s"]
-                del d_h, hs
-            log(f"probe ceiling: random {rf['probe_ceiling_random_per_s'] / 1e9:.1f} G/s, replay of batch 0's hashes "
-                f"{rf.get('probe_ceiling_replay_per_s', 0) / 1e9:.1f} G/s; the scan kernel sustains {rf['scattered_probes_per_s'] / 1e9:.1f} G/s "
-                f"({time.time() - t_c:.1f} s)")
+            if not args.pmc_child:
+                # ONE bound the kernel cannot exceed: the same table serving the same key stream -- batch 0's own
+                # minimizer hashes, in the kernel's order -- to a kernel that does nothing but issue the home-group reads
+                # (dcn_index_probe_ceiling: best of six launch shapes).  Beside it, the same for uniformly random groups (no
+                # reuse at all: every request an L2 miss), which is what the documented 46 G/s stands for.
+                t_c = time.time()
+                rf["probe_ceiling_random_per_s"] = index.probe_ceiling(None, 1 << 27, reps=3)
+                if args.workload == "short":
+                    b0 = batches[0]
+                    pc = dcn.FilterProcessor(index, max_batch_bases=b0.n_bases, max_batch_reads=b0.n_reads)
+                    _, hs, _ = pc.minimizer_hashes_batch(b0.d_bases.cpu().numpy(), b0.d_offsets.cpu().numpy().astype(np.uint64))
+                    pc.close()
+                    d_h = torch.from_numpy(hs.view(np.int64)).to(device)
+                    rf["probe_ceiling_replay_per_s"] = index.probe_ceiling(d_h.data_ptr(), d_h.numel(), reps=3)
+                    rf["probe_ceiling_replay_stream"] = f"the {d_h.numel():,} valid minimizer hashes of batch 0, in read order"
+                    rf["frac_of_probe_ceiling"] = rf["scattered_probes_per_s"] / rf["probe_ceiling_replay_per_s"]
+                    del d_h, hs
+                log(f"probe ceiling: random {rf['probe_ceiling_random_per_s'] / 1e9:.1f} G/s, replay of batch 0's hashes "
+                    f"{rf.get('probe_ceiling_replay_per_s', 0) / 1e9:.1f} G/s; the scan kernel sustains {rf['scattered_probes_per_s'] / 1e9:.1f} G/s "
+                    f"({time.time() - t_c:.1f} s)")
         except Exception as ex:
             log(f"probe ceiling measurement failed: {ex!r}")
         names = {"short": "configs[1]: 150 bp reads vs panhuman-1-sized index, -a 2 -r 0.01, inputs resident in HBM as ASCII",
@@ -952,7 +1223,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(oidx, cores, batches[0], params)
                 port_result = out["cpu_baseline"].pop("_result")
                 log(f"cpu_baseline: {out['cpu_baseline']['value']:.0f} Mbp/s on {cores} cores, decisions match: {out['cpu_baseline']['decisions_match_gpu']}")
-                out["cpu_baseline_tuned"] = cpu_baseline(oidx, cores, batches[0], params, seconds_target=8.0, tuned=True, port_result=port_result)
+                out["cpu_baseline_tuned"] = cpu_baseline(oidx, cores, batches[0], params, seconds_target=4.0, tuned=True, port_result=port_result)
                 del port_result
                 log(f"cpu_baseline_tuned: {out['cpu_baseline_tuned']['value']:.0f} Mbp/s on {cores} cores, equals the port: "
                     f"{out['cpu_baseline_tuned']['equals_port']}, decisions match: {out['cpu_baseline_tuned']['decisions_match_gpu']}")
@@ -979,7 +1250,7 @@ def main():
                     r["decisions_match_gpu"], r["oracle_sample"] = ok, what + f" vs the oracle's {len(oidx):,}-key set (keep, hits, totals)"
                     r["workload"] = names[e]
                     committed_traffic(r["roofline"], e, bs[0].n_bases, int(index.n_keys), args.host_genome)
-                    if "pmc" in extras:  # ... and measured in this run as well (the same batches: same generator, same seed)
+                    if "pmc_legs" in extras:  # ... and measured in this run as well (the same batches: same generator, same seed)
                         apply_live_traffic(r["roofline"], live_traffic(e, args.reads, args.index_keys, args.host_genome))
                     workloads[e] = r
                     del bs
@@ -1075,6 +1346,8 @@ def main():
                     idx3, keys3, hk3, nr3, tb = build_index(genome_dev, UNION_KEYS, local_rank)
                     del keys3
                     for key_, kind_, seed_ in (("union950m", "mixed", 29), ("union950m_paired", "paired", 27)):
+                        if key_ not in extras:
+                            continue
                         bs = make_batches(kind_, genome_dev, args.reads, seed_, device)
                         r, _, _, _ = run_device_workload(idx3, bs, P_PAIRED, 12, 3, 1, device, reserve_long=kind_ == "mixed")
                         b_, o_, u_, nu_ = sample_of(bs[0], 15_000_000)
@@ -1090,7 +1363,7 @@ def main():
                         r["workload"] = f"configs[4]-sized table: {int(idx3.n_keys):,} keys (2^31 groups, 34 GB); {shape}"
                         if kind_ == "mixed":
                             committed_traffic(r["roofline"], "mixed", bs[0].n_bases, int(idx3.n_keys), args.host_genome)
-                            if "pmc" in extras:  # (the child draws its own mixed batches: same generator, another seed)
+                            if "pmc_legs" in extras:  # (the child draws its own mixed batches: same generator, another seed)
                                 apply_live_traffic(r["roofline"], live_traffic("mixed", args.reads, UNION_KEYS, args.host_genome))
                         r["table_build_s"] = tb
                         workloads[key_] = r
@@ -1113,7 +1386,7 @@ def main():
         if cli:
             out["cli"] = cli
         out["bench_wall_s"] = time.time() - T0
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -245,7 +245,7 @@ def file_to_file(index, genome_dev, host_keys_sorted, n_rand, make_reads, make_p
                  sizes=None, log=lambda *a: None, check_reads=200_000):
     """search50 / deplete95 / paired against the bench's panhuman-sized index written as an index FILE"""
     from oracle import oracle as O
-    sizes = sizes or {"search50": 16_000_000, "deplete95": 64_000_000, "paired": 8_000_000}
+    sizes = sizes or {"search50": 16_000_000, "deplete95": 32_000_000, "paired": 8_000_000}
     d = tmp_root()
     out = {}
     try:
@@ -297,7 +297,7 @@ def file_to_file(index, genome_dev, host_keys_sorted, n_rand, make_reads, make_p
             r["decisions_match"] = check(first["seqs"][:nchk], None, deplete, o, nchk)
             r["checked"] = f"ids of the kept records among the first {nchk} reads == the oracle's decisions"
             r["input_generated_s"] = gen_s
-            if cores > 8:  # the same files with three quarters of the CPU share (the tool's default is the reference's: -t 8; the
+            if cores > 8 and os.environ.get("DCN_BENCH_CLI_THREADS_AB"):  # the same files with three quarters of the CPU share (the tool's default is the reference's: -t 8; the
                 # formatters, the library's copy threads and the runtime want the rest: -t 12 beat -t 8 and -t 16 on 16 CPUs)
                 o2 = os.path.join(d, f"{name}.out_t.fq")
                 nt = max(9, cores * 3 // 4)

@@ -36,19 +36,57 @@ __device__ __constant__ uint32_t NT_F[4] = {0x95c60474u, 0x62a02b4cu, 0x82572324
 
 __device__ inline uint32_t rotl32(uint32_t x, uint32_t r) { return __funnelshift_l(x, x, r); }
 
+// Wave-wide scan / reduction on DPP row shifts and row broadcasts (the gfx9 sequence: row_shr 1, 2, 4, 8 inside each row of
+// 16 lanes, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2-3).  No ds_bpermute, hence no per-lane address
+// registers: with __shfl_up / __shfl_xor the six address VGPRs of a scan were computed once and stayed live across phase A
+// (the decisions-only kernel spilled them to scratch).  `old` = 0 is the identity of both + and unsigned max.
+#ifndef DCN_WAVE_OPS_SHFL
+#define DCN_WAVE_OPS_SHFL 0 // 1: the round-1..3 form on __shfl, kept for A/B timing
+#endif
+template <bool MAX>
+__device__ inline uint32_t wave_scan_dpp(uint32_t v) {
+    auto op = [](uint32_t x, uint32_t y) { return MAX ? max(x, y) : x + y; };
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false)); // row_shr:1
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false)); // row_shr:2
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false)); // row_shr:4
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false)); // row_shr:8
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false)); // row_bcast:15 -> rows 1, 3
+    v = op(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false)); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __device__ inline uint32_t wave_inclusive_scan_u32(uint32_t v, int lane) {
+#if DCN_WAVE_OPS_SHFL
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t o = __shfl_up(v, d, 64);
         if (lane >= d) v += o;
     }
     return v;
+#else
+    (void)lane;
+    return wave_scan_dpp<false>(v);
+#endif
 }
 
+// wave-uniform (the value of lane 63 of the max-scan, read into an SGPR)
 __device__ inline uint32_t wave_max_u32(uint32_t v) {
+#if DCN_WAVE_OPS_SHFL
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
     return v;
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp<true>(v), 63);
+#endif
+}
+
+// lane 63's value of an inclusive scan = the wave's total, wave-uniform
+__device__ inline uint32_t wave_last_u32(uint32_t incl) {
+#if DCN_WAVE_OPS_SHFL
+    return __shfl(incl, 63, 64);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#endif
 }
 
 #ifndef DCN_LIST_BY_LANE
@@ -255,7 +293,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
         const uint32_t us_skip = uslot | (skip0 << 8); // what phase B needs of an item's owner lane, in one shuffle
         const uint32_t cnt_eff = cnt - skip0;
         uint32_t incl = wave_inclusive_scan_u32(cnt_eff, lane);
-        uint32_t M = __shfl(incl, 63, 64);
+        uint32_t M = wave_last_u32(incl);
         sh.start[lane] = (uint16_t)(incl - cnt_eff);
         if (lane == 63) sh.start[64] = (uint16_t)M;
         if (!DUMP && cnt_eff) atomicAdd(&sh.items[uslot], cnt_eff);
@@ -857,7 +895,7 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
             // the rest: the undecided lanes' remaining entries, flattened over the wave so that no lane idles
             const uint32_t rem = (nh < need && cnt_eff > R1) ? cnt_eff - R1 : 0u;
             const uint32_t incl = wave_inclusive_scan_u32(rem, lane);
-            const uint32_t M = __shfl(incl, 63, 64);
+            const uint32_t M = wave_last_u32(incl);
             if (M) {
                 sh.start[lane] = (uint16_t)(incl - rem);
                 if (lane == 63) sh.start[64] = (uint16_t)M;

@@ -1,5 +1,9 @@
 // Host-only check of the index file codec (csrc/index_file.cpp): threaded writer vs the byte-by-byte definition of the
 // bincode-2 varint format (src/index.rs:130-164), and the reader on what it wrote.  Built by tests/test_index_file.py.
+//   index_file_test <scratch.idx>                      the self-check below
+//   index_file_test --roundtrip <given.idx> <out.idx>  read a file somebody else wrote (the real bincode 2.0.1, from
+//                                                      tests/golden/crate_vectors.json), write its keys back in the same
+//                                                      order and require the same bytes; prints k, w and the keys
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +26,33 @@ static void ref_varint(std::vector<uint8_t> &o, uint64_t v) {
     for (int i = 0; i < nb; ++i) o.push_back((uint8_t)(v >> (8 * i)));
 }
 
+static std::vector<uint8_t> slurp(const char *path) {
+    std::vector<uint8_t> b;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return b;
+    uint8_t buf[4096];
+    size_t m;
+    while ((m = std::fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + m);
+    std::fclose(f);
+    return b;
+}
+
+static int roundtrip(const char *given, const char *out) {
+    uint8_t k = 0, w = 0;
+    std::vector<uint64_t> keys;
+    if (dcn_read_index_file(given, &k, &w, &keys) != 0) return 4;
+    if (dcn_write_index_file(out, k, w, keys.data(), keys.size()) != 0) return 5;
+    if (slurp(given) != slurp(out)) {
+        std::fprintf(stderr, "the codec does not write back the bytes it was given\n");
+        return 6;
+    }
+    std::printf("roundtrip ok k=%u w=%u n=%zu\n", (unsigned)k, (unsigned)w, keys.size());
+    for (uint64_t v : keys) std::printf("0x%llx\n", (unsigned long long)v);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc == 4 && std::string(argv[1]) == "--roundtrip") return roundtrip(argv[2], argv[3]);
     const char *path = argc > 1 ? argv[1] : "/tmp/index_file_test.idx";
     uint64_t x = 88172645463325252ull;
     auto rnd = [&] { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };

@@ -6,13 +6,23 @@
 //! `raw_positions` is the crate's answer before the reference's ACGT filter, which is what separates
 //! the candidate rules (rotation 1|7, 16|32 compared bits, + | ^) most directly.
 //!
+//! Two more sections come from the reference's OWN public functions (the `deacon` library crate, src/lib.rs:26-33, 276-286),
+//! so nothing of them is restated here:
+//!   * `index_vectors`: `deacon::compute_minimizer_hashes(seq, k, w, entropy_threshold)` = fill_minimizer_hashes,
+//!     src/minimizers.rs:125-191 (IUPAC rewrite, `AsciiSeq` view, ACGT test on the original bytes, entropy floor :73-121);
+//!   * `index_file`: the bytes `deacon::write_minimizers` (src/index.rs:130-164: bincode 2.0.1 `encode_into_std_write`,
+//!     `config::standard()`) writes for a small key set that holds every varint width and its boundary values.
+//!
 //! Output: one JSON document on stdout, schema of tests/golden/oracle_vectors.json plus `raw_positions`:
-//!   {"source": "...", "vectors": [{"k":31,"w":15,"seq":"ACGT...","raw_positions":[..],"positions":[..],"hashes":["0x.."]}]}
+//!   {"source": "...", "vectors": [{"k":31,"w":15,"seq":"ACGT...","raw_positions":[..],"positions":[..],"hashes":["0x.."]}],
+//!    "index_vectors": [{"k":31,"w":15,"entropy_threshold":"0.5","seq":"ACGTN...","hashes":["0x.."]}],
+//!    "index_file": {"k":31,"w":15,"keys_sorted":["0x0",..],"hex":"021f0f.."}}
 //!
 //! Sequences: every `seq` of ../oracle_vectors.json (read at run time, so the two files cannot drift), the
 //! reference's own test literals (tests/filter_tests.rs:43-63, 957-966, 1203), and a seeded set of longer reads.
 
 use packed_seq::SeqVec;
+use rustc_hash::FxHashSet;
 use std::fmt::Write as _;
 
 fn hashes_and_positions(seq: &[u8], k: usize, w: usize) -> (Vec<u32>, Vec<u32>, Vec<u64>) {
@@ -101,6 +111,101 @@ fn vectors_of_oracle_file(path: &str) -> Vec<(usize, usize, String)> {
     out
 }
 
+/// IUPAC codes, both cases, and a few bytes outside the alphabet: what src/minimizers.rs:24-43 rewrites
+fn random_iupac(state: &mut u64, n: usize, ambiguous_per_1024: u64, lower_per_1024: u64) -> String {
+    const AMBIG: &[u8] = b"RYSWKMBDHVNX-";
+    let mut s = String::with_capacity(n);
+    for _ in 0..n {
+        let r = splitmix(state);
+        let mut c = [b'A', b'C', b'G', b'T'][(r & 3) as usize];
+        if (r >> 8) % 1024 < ambiguous_per_1024 {
+            c = AMBIG[((r >> 40) % AMBIG.len() as u64) as usize];
+        }
+        if c.is_ascii_alphabetic() && (r >> 24) % 1024 < lower_per_1024 {
+            c |= 0x20;
+        }
+        s.push(c as char);
+    }
+    s
+}
+
+/// low-complexity stretches between random ones: minimizers on both sides of an entropy floor
+fn low_complexity(state: &mut u64, n: usize) -> String {
+    let mut s = String::with_capacity(n);
+    while s.len() < n {
+        let r = splitmix(state);
+        let run = 20 + (r >> 8) as usize % 60;
+        match r & 3 {
+            0 => s.push_str(&"A".repeat(run)),
+            1 => s.push_str(&"AC".repeat(run / 2)),
+            2 => s.push_str(&"AAAT".repeat(run / 4)),
+            _ => s.push_str(&random_seq(state, run, 0, 0)),
+        }
+    }
+    s.truncate(n);
+    s
+}
+
+/// index side: the reference's own fill_minimizer_hashes (src/minimizers.rs:125-191) through its public re-export
+fn index_vectors(out: &mut String) {
+    let mut st = 20261005u64;
+    let mut cases: Vec<(u8, u8, &str, String)> = Vec::new(); // k, w, entropy threshold as text, sequence
+    for &(k, w) in &[(31u8, 15u8), (15, 11), (41, 15), (21, 9), (9, 5), (32, 16), (56, 2)] {
+        for &thr in &["0.0", "0.5"] {
+            cases.push((k, w, thr, random_iupac(&mut st, 400, 0, 0)));
+            cases.push((k, w, thr, random_iupac(&mut st, 1500, 24, 200)));
+            cases.push((k, w, thr, low_complexity(&mut st, 1200)));
+        }
+    }
+    cases.push((31, 15, "0.25", low_complexity(&mut st, 3000)));
+    cases.push((31, 15, "0.9", random_iupac(&mut st, 3000, 8, 0)));
+    cases.push((31, 15, "0.0", "ACGTNNNNACGT".repeat(12)));           // non-ACGT k-mers on the original bytes
+    cases.push((31, 15, "0.0", random_iupac(&mut st, 40, 0, 0)));     // k <= len < k+w-1: no window
+    cases.push((31, 15, "0.0", random_iupac(&mut st, 20, 0, 0)));     // len < k (:136-139)
+    cases.push((31, 15, "0.0", random_iupac(&mut st, 70_000, 2, 20))); // beyond 65,536 bases
+    out.push_str(" \"index_vectors\": [\n");
+    for (i, (k, w, thr, seq)) in cases.iter().enumerate() {
+        let t: f32 = thr.parse().unwrap();
+        let hashes = deacon::compute_minimizer_hashes(seq.as_bytes(), *k, *w, t);
+        let hx = hashes.iter().map(|h| format!("\"{:#x}\"", h)).collect::<Vec<_>>().join(", ");
+        let _ = write!(
+            out,
+            "  {{\"k\": {}, \"w\": {}, \"entropy_threshold\": \"{}\", \"seq\": \"{}\", \"hashes\": [{}]}}{}\n",
+            k, w, thr, seq, hx, if i + 1 == cases.len() { "" } else { "," }
+        );
+    }
+    out.push_str(" ],\n");
+}
+
+/// index file: the reference's own writer (src/index.rs:130-164 through src/lib.rs:280-286), bytes as hex
+fn index_file(out: &mut String) {
+    let mut keys: Vec<u64> = vec![0, 1, 250, 251, 252, 65_535, 65_536, 0xFFFF_FFFF, 0x1_0000_0000, u64::MAX, u64::MAX - 1,
+                                  0xC77B3ABB6F87ACD9, 0x2FBC593564DB792E]; // (the last two: XXH3 of k-mer values 0 and 1)
+    let mut st = 20261006u64;
+    for _ in 0..300 {
+        keys.push(splitmix(&mut st));               // 9-byte encodings, as nearly all real hashes
+    }
+    for _ in 0..20 {
+        keys.push(splitmix(&mut st) >> 40);          // 5-byte encodings
+        keys.push(splitmix(&mut st) >> 52);          // 3-byte and 1-byte encodings
+    }
+    let set: FxHashSet<u64> = keys.iter().copied().collect();
+    let header = deacon::IndexHeader::new(31, 15);
+    let path = std::env::temp_dir().join(format!("dump_crate_vectors_{}.idx", std::process::id()));
+    deacon::write_minimizers(&set, &header, Some(&path)).expect("write_minimizers");
+    let bytes = std::fs::read(&path).expect("read the index file back");
+    // and what the reference's own loader makes of it (src/index.rs:80-107)
+    let (loaded, h2) = deacon::load_minimizers(&path).expect("load_minimizers");
+    let _ = std::fs::remove_file(&path);
+    let loaded = loaded.expect("a key set");
+    assert!(loaded == set && h2.kmer_length() == 31 && h2.window_size() == 15);
+    let mut sorted: Vec<u64> = set.iter().copied().collect();
+    sorted.sort_unstable();
+    let kx = sorted.iter().map(|h| format!("\"{:#x}\"", h)).collect::<Vec<_>>().join(", ");
+    let hex = bytes.iter().map(|b| format!("{:02x}", b)).collect::<String>();
+    let _ = write!(out, " \"index_file\": {{\"k\": 31, \"w\": 15, \"keys_sorted\": [{}], \"hex\": \"{}\"}}\n", kx, hex);
+}
+
 fn main() {
     let mut cases: Vec<(usize, usize, String)> = vectors_of_oracle_file("../oracle_vectors.json");
     // the reference's own literals
@@ -126,7 +231,7 @@ fn main() {
     cases.push((31, 15, random_seq(&mut st, 70_000, 1, 0)));
 
     let mut out = String::new();
-    out.push_str("{\n \"source\": \"simd-minimizers 1.3.0 + packed-seq 3.2.1 + xxhash-rust 0.8.15, calls of src/filter_common.rs:238-307\",\n \"vectors\": [\n");
+    out.push_str("{\n \"source\": \"simd-minimizers 1.3.0 + packed-seq 3.2.1 + xxhash-rust 0.8.15, calls of src/filter_common.rs:238-307; index_vectors / index_file: the deacon crate's own compute_minimizer_hashes / write_minimizers (bincode 2.0.1)\",\n \"vectors\": [\n");
     for (i, (k, w, seq)) in cases.iter().enumerate() {
         if (k + w - 1) % 2 == 0 || seq.len() < k + w - 1 {
             continue;
@@ -140,8 +245,11 @@ fn main() {
             k, w, seq, join(&raw), join(&pos), hx, if i + 1 == cases.len() { "" } else { "," }
         );
     }
-    out.push_str(" ]\n}\n");
+    out.push_str(" ],\n");
     // a trailing comma before the closing bracket (when the last case was skipped) would not be JSON
-    let out = out.replace(",\n ]", "\n ]");
+    let mut out = out.replace(",\n ],", "\n ],");
+    index_vectors(&mut out);
+    index_file(&mut out);
+    out.push_str("}\n");
     print!("{}", out);
 }

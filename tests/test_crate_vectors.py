@@ -1,30 +1,47 @@
-"""Consumes tests/golden/crate_vectors.json -- the output of tests/golden/dump_crate_vectors (a Rust program that
-calls the real simd-minimizers 1.3.0 / packed-seq 3.2.1 / xxhash-rust 0.8.15 exactly as src/filter_common.rs:238-307
-does).  The build image has no Rust toolchain, so the file is absent here and these tests skip; with the file in
-place they are the value-level pin the oracle lacks ("parity unpinned"):
+"""Consumes tests/golden/crate_vectors.json -- the output of tests/golden/dump_crate_vectors, a Rust program that calls
+the real simd-minimizers 1.3.0 / packed-seq 3.2.1 / xxhash-rust 0.8.15 exactly as src/filter_common.rs:238-307 does and,
+for the index side, the reference's OWN public functions (compute_minimizer_hashes = src/minimizers.rs:125-191,
+write_minimizers = src/index.rs:130-164 on bincode 2.0.1).  The build image has no Rust toolchain, so the file is absent
+here and the tests that need it skip; with the file in place they are the value-level pin the oracle lacks ("parity
+unpinned") for A2/A4/A6 (filter side), A11 (index side) and A9 (index file):
 
-  * the oracle must reproduce every vector under at least one of its eight settings, the test names which, and it
-    fails unless that setting is the default (fix = change the default, see dump_crate_vectors/Cargo.toml);
-  * on the GPU the product, switched to the same setting, must reproduce every vector as well.
+  * the oracle must reproduce every filter-side vector under at least one of its eight settings, the test names which, and
+    it fails unless that setting is the default (fix = change the default, see dump_crate_vectors/Cargo.toml);
+  * the oracle's index-side builder must reproduce every index vector (IUPAC input, lower case, entropy floors) under that
+    same setting;
+  * the reference-written index file must decode -- by the oracle's reader and by the product's host codec
+    (csrc/index_file.cpp) -- to exactly the key set it was made from, and both writers must give back its bytes when handed
+    the keys in the file's order;
+  * on the GPU the product, switched to the same setting, must reproduce the filter-side vectors (dcn_minimizer_hashes_batch),
+    the index-side ones (dcn_index_build -> key set), load the file (dcn_index_from_file) and write one
+    (dcn_index_write_file) that decodes to the same set with the same length.
+
+So that the consuming code itself is exercised here, every consumer also runs on a STAND-IN file of the same schema that
+the oracle makes (tmp_path; never committed, and proof of nothing but the plumbing).
 """
 import json
 import os
+import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import GOLDEN
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(GOLDEN, "crate_vectors.json")
 needs_file = pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/crate_vectors.json not generated "
                                 "(needs cargo: tests/golden/dump_crate_vectors)")
 
 
-def load():
-    vec = json.load(open(PATH))["vectors"]
-    assert len(vec) >= 10
-    return vec
+def load(path=PATH, section="vectors"):
+    doc = json.load(open(path))
+    if section not in doc:
+        pytest.skip(f"{os.path.basename(path)} has no '{section}' section (written by an older dump_crate_vectors)")
+    return doc[section]
 
 
+# ---- the consumers (path in, assertion out) ------------------------------------------------------------------------------
 def matching_variants(oracle, vec):
     ok = []
     try:
@@ -47,23 +64,85 @@ def matching_variants(oracle, vec):
     return ok
 
 
-@needs_file
-def test_oracle_reproduces_the_crates(oracle):
-    ok = matching_variants(oracle, load())
+def the_variant(oracle, path):
+    """the setting the filter-side vectors of `path` select (the default when it is among them)"""
+    vec = load(path)
+    assert len(vec) >= 10
+    ok = matching_variants(oracle, vec)
     assert ok, "no setting of the oracle reproduces the crates' vectors: a rule beyond the three switches differs"
+    return (oracle.DEFAULT_VARIANT if oracle.DEFAULT_VARIANT in ok else ok[0]), ok
+
+
+def check_oracle_filter_side(oracle, path):
+    v, ok = the_variant(oracle, path)
     assert oracle.DEFAULT_VARIANT in ok, (
         f"the crates follow {ok} (rotation, compared bits, combine; every setting listed reproduces all vectors), not "
         f"the default {oracle.DEFAULT_VARIANT}: change the defaults in oracle/deacon_oracle.c and csrc/scan.hip")
 
 
-@needs_file
-@pytest.mark.gpu
-def test_gpu_reproduces_the_crates(oracle, dcn):
-    import numpy as np
-    vec = load()
-    ok = matching_variants(oracle, vec)
-    assert ok
-    v = oracle.DEFAULT_VARIANT if oracle.DEFAULT_VARIANT in ok else ok[0]
+def check_oracle_index_side(oracle, path):
+    """A11: fill_minimizer_hashes (src/minimizers.rs:125-191) as the reference itself computed it"""
+    vec = load(path, "index_vectors")
+    assert len(vec) >= 10
+    v, _ = the_variant(oracle, path)
+    oracle.set_variant(*v)
+    try:
+        for i, x in enumerate(vec):
+            got = oracle.index_minimizer_hashes(x["seq"].encode(), x["k"], x["w"], float(x["entropy_threshold"]))
+            assert [hex(int(q)) for q in got] == x["hashes"], (i, x["k"], x["w"], x["entropy_threshold"], len(x["seq"]))
+    finally:
+        oracle.set_variant(*oracle.DEFAULT_VARIANT)
+
+
+def file_of(path, tmp_path):
+    f = load(path, "index_file")
+    raw = bytes.fromhex(f["hex"])
+    p = tmp_path / "reference_written.idx"
+    p.write_bytes(raw)
+    keys = np.array([int(x, 16) for x in f["keys_sorted"]], dtype=np.uint64)
+    assert len(np.unique(keys)) == len(keys)
+    return f, raw, str(p), keys
+
+
+def build_codec_tool(tmp_path):
+    exe = tmp_path / "index_file_test"
+    if not exe.exists():
+        csrc = os.path.join(ROOT, "deacon-server_amd", "csrc")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", "-fno-gpu-rdc",
+                               "-Wno-unused-value", "-I", csrc, "-I", os.path.join(ROOT, "include"),
+                               os.path.join(csrc, "index_file.cpp"), os.path.join(ROOT, "tests", "cpp", "index_file_test.cpp"),
+                               "-o", str(exe), "-lpthread"])
+    return str(exe)
+
+
+def check_index_file_on_the_host(oracle, path, tmp_path):
+    """A9: the bytes bincode 2.0.1 wrote (src/index.rs:130-164) vs the oracle's codec and the product's host codec"""
+    f, raw, p, keys = file_of(path, tmp_path)
+    assert raw[:3] == bytes([2, f["k"], f["w"]])                               # IndexHeader: three plain bytes (:17-31)
+    got = oracle.Index.read(p)
+    assert (got.k, got.w) == (f["k"], f["w"]) and len(got) == len(keys)
+    assert (np.sort(got.keys()) == keys).all()
+    # file order -> the same bytes from the oracle's writer
+    n = oracle.C.c_uint64()
+    kk, ww = oracle.C.c_uint8(), oracle.C.c_uint8()
+    assert oracle.lib().dor_index_read_header(os.fsencode(p), oracle.C.byref(kk), oracle.C.byref(ww), oracle.C.byref(n)) == 0
+    in_order = np.zeros(max(n.value, 1), np.uint64)
+    c = oracle.lib().dor_index_read_keys(os.fsencode(p), oracle._p(in_order, oracle.C.c_uint64), len(in_order))
+    assert c == len(keys)
+    back = tmp_path / "oracle_written.idx"
+    assert oracle.lib().dor_index_write(os.fsencode(str(back)), f["k"], f["w"], oracle._p(in_order, oracle.C.c_uint64), c) == 0
+    assert back.read_bytes() == raw
+    # the product's host codec: reads it, writes the keys back in the same order, byte for byte
+    out = subprocess.run([build_codec_tool(tmp_path), "--roundtrip", p, str(tmp_path / "codec_written.idx")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.split()
+    assert out.stdout.startswith(f"roundtrip ok k={f['k']} w={f['w']} n={len(keys)}")
+    assert [int(x, 16) for x in lines[5:]] == in_order[:c].tolist()
+
+
+def check_gpu_filter_side(oracle, dcn, path):
+    vec = load(path)
+    v, _ = the_variant(oracle, path)
     dcn.set_minimizer_variant(*v)
     try:
         by_kw = {}
@@ -82,3 +161,124 @@ def test_gpu_reproduces_the_crates(oracle, dcn):
             idx.close()
     finally:
         dcn.set_minimizer_variant(*oracle.DEFAULT_VARIANT)
+
+
+def check_gpu_index_side(oracle, dcn, path, tmp_path):
+    """dcn_index_build on every index vector -> the set of its hashes; dcn_index_from_file / _write_file on the file"""
+    v, _ = the_variant(oracle, path)
+    dcn.set_minimizer_variant(*v)
+    try:
+        for i, x in enumerate(load(path, "index_vectors")):
+            idx = dcn.Index.build([x["seq"].encode()], x["k"], x["w"], entropy_threshold=float(x["entropy_threshold"]))
+            want = np.unique(np.array([int(q, 16) for q in x["hashes"]], dtype=np.uint64))
+            assert (np.sort(idx.keys()) == want).all(), (i, x["k"], x["w"], x["entropy_threshold"])
+            idx.close()
+    finally:
+        dcn.set_minimizer_variant(*oracle.DEFAULT_VARIANT)
+    f, raw, p, keys = file_of(path, tmp_path)
+    idx = dcn.Index.from_file(p)
+    assert (idx.k, idx.w, idx.n_keys) == (f["k"], f["w"], len(keys)) and (np.sort(idx.keys()) == keys).all()
+    out = tmp_path / "product_written.idx"
+    idx.write(str(out))
+    idx.close()
+    assert out.stat().st_size == len(raw) and out.read_bytes()[:3] == raw[:3]      # same header, same total of varint widths
+    back = oracle.Index.read(str(out))
+    assert (np.sort(back.keys()) == keys).all()
+
+
+# ---- with the real file ---------------------------------------------------------------------------------------------------
+@needs_file
+def test_oracle_reproduces_the_crates(oracle):
+    check_oracle_filter_side(oracle, PATH)
+
+
+@needs_file
+def test_oracle_index_side_reproduces_the_reference(oracle):
+    check_oracle_index_side(oracle, PATH)
+
+
+@needs_file
+def test_index_file_written_by_bincode_is_read_and_rewritten_byte_for_byte(oracle, tmp_path):
+    check_index_file_on_the_host(oracle, PATH, tmp_path)
+
+
+@needs_file
+@pytest.mark.gpu
+def test_gpu_reproduces_the_crates(oracle, dcn):
+    check_gpu_filter_side(oracle, dcn, PATH)
+
+
+@needs_file
+@pytest.mark.gpu
+def test_gpu_index_side_reproduces_the_reference(oracle, dcn, tmp_path):
+    check_gpu_index_side(oracle, dcn, PATH, tmp_path)
+
+
+# ---- the same consumers on an oracle-made stand-in (plumbing only) -------------------------------------------------------------
+def splitmix(state):
+    state[0] = (state[0] + 0x9E3779B97F4A7C15) & (2**64 - 1)
+    z = state[0]
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+    return z ^ (z >> 31)
+
+
+def stand_in(oracle, path):
+    """a file of crate_vectors.json's schema with the ORACLE's answers in it: what the dumper's output looks like"""
+    rng = np.random.default_rng(7)
+    doc = {"source": "STAND-IN made by the oracle (tests/test_crate_vectors.py)", "vectors": [], "index_vectors": []}
+    for x in json.load(open(os.path.join(GOLDEN, "oracle_vectors.json")))["vectors"]:
+        seq = x["seq"].encode()
+        h, p = oracle.minimizer_hashes_and_positions(seq, x["k"], x["w"])
+        doc["vectors"].append({"k": x["k"], "w": x["w"], "seq": x["seq"],
+                               "raw_positions": oracle.canonical_minimizer_positions(seq, x["k"], x["w"]).tolist(),
+                               "positions": p.tolist(), "hashes": [hex(int(q)) for q in h]})
+    alpha = np.frombuffer(b"ACGTACGTACGTACGTRYSWKMBDHVNX-acgtn", dtype=np.uint8)
+    for k, w in ((31, 15), (15, 11), (41, 15), (9, 5)):
+        for thr in ("0.0", "0.5"):
+            for n in (40, 400, 3000):
+                seq = alpha[rng.integers(0, len(alpha), n)].tobytes()
+                if n == 3000:
+                    seq = seq[:1000] + b"A" * 300 + b"AC" * 200 + seq[1700:]
+                doc["index_vectors"].append({"k": k, "w": w, "entropy_threshold": thr, "seq": seq.decode(),
+                                             "hashes": [hex(int(q)) for q in oracle.index_minimizer_hashes(seq, k, w, float(thr))]})
+    st = [20261006]
+    keys = [0, 1, 250, 251, 252, 65535, 65536, 0xFFFFFFFF, 0x100000000, 2**64 - 1, 2**64 - 2]
+    keys += [splitmix(st) for _ in range(300)] + [splitmix(st) >> 40 for _ in range(20)] + [splitmix(st) >> 52 for _ in range(20)]
+    keys = np.unique(np.array(keys, dtype=np.uint64))
+    tmp = path + ".idx"
+    shuffled = keys[rng.permutation(len(keys))]                       # a hash set's iteration order is arbitrary
+    assert oracle.lib().dor_index_write(os.fsencode(tmp), 31, 15, oracle._p(shuffled, oracle.C.c_uint64), len(shuffled)) == 0
+    doc["index_file"] = {"k": 31, "w": 15, "keys_sorted": [hex(int(q)) for q in keys], "hex": open(tmp, "rb").read().hex()}
+    os.unlink(tmp)
+    json.dump(doc, open(path, "w"))
+    return path
+
+
+def test_consumers_run_on_an_oracle_made_stand_in(oracle, tmp_path):
+    p = stand_in(oracle, str(tmp_path / "stand_in.json"))
+    check_oracle_filter_side(oracle, p)
+    check_oracle_index_side(oracle, p)
+    check_index_file_on_the_host(oracle, p, tmp_path)
+    # and they do notice a wrong value: one hash, one file byte
+    doc = json.load(open(p))
+    bad = json.loads(json.dumps(doc))
+    x = next(v for v in bad["index_vectors"] if v["hashes"])
+    x["hashes"][0] = hex(int(x["hashes"][0], 16) ^ 1)
+    json.dump(bad, open(p, "w"))
+    with pytest.raises(AssertionError):
+        check_oracle_index_side(oracle, p)
+    bad = json.loads(json.dumps(doc))
+    raw = bytearray.fromhex(bad["index_file"]["hex"])
+    raw[-1] ^= 0x40
+    bad["index_file"]["hex"] = raw.hex()
+    json.dump(bad, open(p, "w"))
+    with pytest.raises(AssertionError):
+        check_index_file_on_the_host(oracle, p, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gpu_consumers_run_on_an_oracle_made_stand_in(oracle, dcn, tmp_path):
+    p = stand_in(oracle, str(tmp_path / "stand_in.json"))
+    check_gpu_filter_side(oracle, dcn, p)
+    check_gpu_index_side(oracle, dcn, p, tmp_path)

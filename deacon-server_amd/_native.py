@@ -63,6 +63,7 @@ _u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_
 _vp = C.c_void_p
 
 _SIGNATURES = {
+    "dcn_abi_version": (C.c_int, [_u32p, _u32p]),
     "dcn_version": (C.c_char_p, []),
     "dcn_last_error": (C.c_char_p, []),
     "dcn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -91,6 +92,11 @@ _SIGNATURES = {
                                                  _u64p]),
     "dcn_pack_ascii": (C.c_int, [_vp, C.c_uint64, _vp, _vp, _u32p]),
     "dcn_stats_allreduce": (C.c_int, [C.POINTER(_vp), C.c_int, _u64p]),
+    "dcn_comm_available": (C.c_int, []),
+    "dcn_comm_unique_id": (C.c_int, [_vp]),
+    "dcn_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "dcn_stats_allreduce_rccl": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, _u64p]),
+    "dcn_comm_destroy": (None, [_vp]),
     "dcn_index_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "dcn_index_memory": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "dcn_index_clone": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
@@ -110,6 +116,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+ABI = (1, 1)  # DCN_ABI_MAJOR, the DCN_ABI_MINOR these signatures need
 
 
 def lib():
@@ -126,6 +133,10 @@ def lib():
         f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
         f.restype = res
         f.argtypes = args
+    major, minor = C.c_uint32(), C.c_uint32()
+    if L.dcn_abi_version(C.byref(major), C.byref(minor)) != 0 or (major.value, minor.value >= ABI[1]) != (ABI[0], True):
+        raise ImportError(f"{LIB_PATH} has ABI {major.value}.{minor.value}; these bindings were written against {ABI[0]}.{ABI[1]} "
+                          "(include/deacon_hip.h: DCN_ABI_MAJOR / DCN_ABI_MINOR)")
     _lib = L
     return L
 

@@ -27,7 +27,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
-#define DCN_VERSION_STRING "deacon-hip 0.3.0 (gfx950)"
+#define DCN_VERSION_STRING "deacon-hip 0.4.0 (gfx950)"
 
 // ----------------------------------------------------------------------------------------------------
 // errors
@@ -42,6 +42,13 @@ int dcn_fail(int code, const std::string &msg) {
 
 extern "C" const char *dcn_last_error(void) { return g_last_error.c_str(); }
 extern "C" const char *dcn_version(void) { return DCN_VERSION_STRING; }
+
+extern "C" int dcn_abi_version(uint32_t *major, uint32_t *minor) {
+    if (!major || !minor) return dcn_fail(DCN_ERR_ARG, "dcn_abi_version: NULL output");
+    *major = DCN_ABI_MAJOR;
+    *minor = DCN_ABI_MINOR;
+    return DCN_OK;
+}
 
 extern "C" int dcn_device_count(int *count) {
     if (!count) return dcn_fail(DCN_ERR_ARG, "count is NULL");
@@ -71,6 +78,11 @@ static int check_kw(uint8_t k, uint8_t w) {
     if (w < 1) return dcn_fail(DCN_ERR_ARG, "w must be >= 1");
     if (((uint32_t)k + w - 1) % 2 == 0)
         return dcn_fail(DCN_ERR_ARG, "Constraint violated: k + w - 1 must be odd (src/index.rs:186-194)");
+    // every index passes through here when it is made, and captures the process's rule then: a rule other than the default
+    // runs the generic kernel, whose window ring holds two u64 keys per slot in LDS (scan.hip) -- refused now, not at the
+    // first filter call
+    if (dcn_current_variant() != DCN_VARIANT_DEFAULT && w > 128)
+        return dcn_fail(DCN_ERR_ARG, "minimizer variant: w <= 128 under a non-default rule (dcn_set_minimizer_variant)");
     return DCN_OK;
 }
 
@@ -735,11 +747,24 @@ int grow_run_slots(dcn_ctx *c) {
     // (a batch that was in flight beside the one that made the context switch over reports the same overflow, from its
     // run under the old geometry: it is simply run again)
     if (c->rec_shift == 0) return DCN_OK;
-    uint64_t *neu = nullptr;
-    DCN_TRY(dev_alloc(&neu, c->max_bases + 128, "rec_hash (one slot per window)"));
-    if (c->d_rec_hash && !((char *)c->d_rec_hash >= c->d_slab && (char *)c->d_rec_hash < c->d_slab + c->slab_bytes)) hipFree(c->d_rec_hash);
-    c->d_rec_hash = neu;
+    // The old array goes first (the caller has synchronized the stream: nothing reads it any more), so the peak is the
+    // new 8 B per base and not 8 + 2: on a context sized close to the card the larger array alone may still fit.
+    const bool in_slab = c->d_rec_hash && (char *)c->d_rec_hash >= c->d_slab && (char *)c->d_rec_hash < c->d_slab + c->slab_bytes;
+    if (c->d_rec_hash && !in_slab) hipFree(c->d_rec_hash);
+    c->d_rec_hash = nullptr;
+    const uint32_t old_shift = c->rec_shift;
     c->rec_shift = 0;
+    int rc = dev_alloc(&c->d_rec_hash, c->max_bases + 128, "rec_hash (one slot per window)");
+    if (rc != DCN_OK) { // back to an array of the old geometry, so that the context stays usable for batches that fit it
+        c->rec_shift = old_shift;
+        int rc2 = dev_alloc(&c->d_rec_hash, (c->max_bases >> old_shift) + 256, "rec_hash");
+        return rc2 != DCN_OK ? rc2 : rc;
+    }
+    static std::atomic<bool> said{false};
+    if (!said.exchange(true) && getenv("DCN_QUIET") == nullptr)
+        std::fprintf(stderr, "deacon-hip: a unit's hits outgrew its run of the record array; this context now keeps one slot per window "
+                             "(%.2f GB instead of %.2f GB of device memory)\n", (c->max_bases + 128) * 8e-9,
+                     ((c->max_bases >> old_shift) + 256) * 8e-9);
     return DCN_OK;
 }
 
@@ -1145,6 +1170,10 @@ extern "C" int dcn_ctx_create(const dcn_index *index, uint64_t max_batch_bases, 
     // in more than every fourth window of a wave to fill its run -- real sequence has a minimizer in every eighth -- and a
     // batch that does (w = 1, say) is run again with one slot per window (grow_run_slots).  DCN_REC_SHIFT = 0..3 fixes it.
     c->rec_shift = 2;
+    // ... unless the index's window makes that likely from the start: the density of minimizers is 2 / (w + 1), and low-
+    // complexity sequence ties its way to a hit in every window or two (leftmost / rightmost alternate); from w <= 7 on
+    // (2 / (w + 1) >= 1/4) the context starts with one slot per window instead of finding out in mid-run
+    if (index->w <= 7) c->rec_shift = 0;
     if (const char *rs = getenv("DCN_REC_SHIFT")) c->rec_shift = (uint32_t)std::min(3, std::max(0, atoi(rs)));
     uint64_t MR = max_batch_reads;
     // DCN_CTX_SLAB=1 (experiment, profiles/placement_order.py): the fixed-size buffers below come out of ONE allocation,

@@ -259,20 +259,24 @@ __global__ __launch_bounds__(256) void probe_ceiling_kernel(dcn_table_view t, co
 template <int U, bool NT>
 int time_probe_ceiling(const dcn_index *idx, const uint64_t *d_keys, uint64_t n, uint32_t reps, uint32_t blocks,
                        uint64_t *d_sink, hipStream_t stream, double *rate) {
-    hipEvent_t a, b;
-    DCN_HIP(hipEventCreate(&a));
-    DCN_HIP(hipEventCreate(&b));
+    struct Events { // destroyed on every way out, the DCN_HIP early returns included
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() {
+            if (a) hipEventDestroy(a);
+            if (b) hipEventDestroy(b);
+        }
+    } ev;
+    DCN_HIP(hipEventCreate(&ev.a));
+    DCN_HIP(hipEventCreate(&ev.b));
     hipLaunchKernelGGL((probe_ceiling_kernel<U, NT>), dim3(blocks), dim3(256), 0, stream, idx->view(), d_keys, n, 1ull, d_sink);
-    DCN_HIP(hipEventRecord(a, stream));
+    DCN_HIP(hipEventRecord(ev.a, stream));
     for (uint32_t r = 0; r < reps; ++r)  // another salt per repetition: a generated stream never re-probes the lines of the last one
         hipLaunchKernelGGL((probe_ceiling_kernel<U, NT>), dim3(blocks), dim3(256), 0, stream, idx->view(), d_keys, n,
                            0x9E3779B97F4A7C15ull * (r + 2), d_sink);
-    DCN_HIP(hipEventRecord(b, stream));
-    DCN_HIP(hipEventSynchronize(b));
+    DCN_HIP(hipEventRecord(ev.b, stream));
+    DCN_HIP(hipEventSynchronize(ev.b));
     float ms = 0;
-    DCN_HIP(hipEventElapsedTime(&ms, a, b));
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    DCN_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
     DCN_HIP(hipGetLastError());
     *rate = ms > 0 ? (double)n * reps / (ms * 1e-3) : 0.0;
     return DCN_OK;

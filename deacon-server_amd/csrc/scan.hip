@@ -562,9 +562,11 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                     __syncthreads();
                 }
                 // hits of every other unit: appended to the unit's RUN in the record array.  The array has one slot per
-                // base of the batch stream; the run of (this wave, unit) starts at the slot of the first window of the
-                // unit's first tile in this wave and can take one entry per window of the unit's tiles here -- it can
-                // neither overflow nor reach another run.  Its hits fill it from the front in item order.  No global
+                // 2^rec_shift bases of the batch stream; the run of (this wave, unit) starts at the slot of the first window of
+                // the unit's first tile in this wave and holds sh.ucap entries, one per 2^rec_shift windows of the unit's
+                // tiles here: it cannot reach another run, and with rec_shift > 0 it CAN fill up (homopolymers and short-
+                // period repeats give a hit every window or two) -- then status->run_overflow is raised and the host runs
+                // the batch again with one slot per window (api.hip, grow_run_slots).  Hits fill it from the front in item order.  No global
                 // atomics: the running length lives in LDS, and since items are in flat order the hits of one unit
                 // sit in adjacent lanes of a round.  plan.hip's distinct pass reads the runs back (coalesced).
                 // A zero hash (0 marks an empty set slot there) is flagged per unit instead of counted there.

@@ -42,6 +42,49 @@ def allreduce_counters(stats, device=None, group=None):
     return dict(zip(STAT_NAMES, (int(x) for x in t.cpu().tolist())))
 
 
+class Comm:
+    """RCCL communicator of the C ABI (dcn_comm_*): what a host that is not Python uses for the path's one collective.
+    `exchange(id_bytes_or_None) -> id_bytes` hands rank 0's 128-byte id to every rank (torch.distributed.broadcast_object_list,
+    a file, MPI ...: the library does not care).  Creating it is a collective call."""
+
+    def __init__(self, world_size, rank, device, exchange):
+        import ctypes as C
+
+        from . import _native as N
+        self._N, self._h = N, None
+        N.check(N.lib().dcn_comm_available())
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            N.check(N.lib().dcn_comm_unique_id(ident))
+        raw = exchange(bytes(ident) if rank == 0 else None)
+        if len(raw) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        N.check(N.lib().dcn_comm_create(ident, world_size, rank, device, C.byref(h)))
+        self._h = h
+
+    def allreduce_counters(self, processors):
+        """sum of the six counters over these FilterProcessors and over all ranks -> dict"""
+        import ctypes as C
+        N = self._N
+        ctxs = (C.c_void_p * max(len(processors), 1))(*[p._h for p in processors])
+        out = (C.c_uint64 * len(STAT_NAMES))()
+        N.check(N.lib().dcn_stats_allreduce_rccl(self._h, ctxs, len(processors), out))
+        return dict(zip(STAT_NAMES, (int(x) for x in out)))
+
+    def close(self):
+        if self._h is not None:
+            self._N.lib().dcn_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def gather_keep_in_order(local_batches, n_units, batch_units, group=None, device=None):
     """local_batches: {batch_seq: bool array} of this rank -> keep bitmap of the whole job in unit order
     (identical on every rank).  Host-side ordered merge by batch sequence number."""

@@ -63,6 +63,15 @@ enum {
 };
 
 /* ---- library ------------------------------------------------------------------------------------ */
+/* ABI version of this header.  MAJOR changes whenever the signature of an exported function or the layout of a struct
+ * changes (a binding built against another major must refuse to run: its calls would pass the wrong arguments), MINOR
+ * when entry points are added.  History: 0.x = the headers before versioning (dcn_pack_ascii took four arguments there);
+ * 1.0 = dcn_pack_ascii(bases, n_bases, packed, invmask, saw_newline); 1.1 = dcn_abi_version, dcn_comm_* / dcn_stats_allreduce_rccl. */
+#define DCN_ABI_MAJOR 1
+#define DCN_ABI_MINOR 1
+/* What the loaded library was built as: a binding asserts *major == DCN_ABI_MAJOR it was written against and
+ * *minor >= the minor it needs, before its first other call (no reference counterpart: the reference is one crate). */
+int dcn_abi_version(uint32_t *major, uint32_t *minor);
 const char *dcn_version(void);
 const char *dcn_last_error(void);
 int dcn_device_count(int *count);
@@ -198,8 +207,10 @@ int dcn_filter_batch(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets
  * (src/local_filter.rs:696-709); here ONE caller thread keeps up to two batches in flight per context.
  * submit validates the batch, enqueues its copies and kernels and returns a ticket; wait(ticket) blocks until the
  * batch is done, delivers keep/hits/total and adds the batch's six counters to the context's.  All input and
- * output arrays must stay valid and unmodified until wait returns.  A third submit without a wait fails with
- * DCN_ERR_CAPACITY.  Tickets may be waited for in any order. */
+ * output arrays must stay valid and unmodified until wait returns, and the CONTENTS of keep/hits/total are undefined
+ * until then: results of early chunks are copied out while later chunks are still being prepared, and a batch that
+ * has to be run again (a newline found while packing, a run of the record array that overflowed) overwrites them.
+ * A third submit without a wait fails with DCN_ERR_CAPACITY.  Tickets may be waited for in any order. */
 int dcn_filter_batch_submit(dcn_ctx *ctx, const uint8_t *bases, const uint64_t *offsets, const uint32_t *unit_id,
                             uint32_t n_reads, const dcn_params *params, uint8_t *keep, uint32_t *hits,
                             uint32_t *total, uint64_t *ticket);
@@ -284,6 +295,23 @@ int dcn_ctx_reset_stats(dcn_ctx *ctx);
  * the merge of the per-worker ProcessingStats at src/local_filter.rs:388-396.  In-process contexts share an address
  * space, so this is a host sum; one-process-per-GPU jobs reduce the same six words with RCCL (bench.py). */
 int dcn_stats_allreduce(dcn_ctx *const *ctxs, int n_ctx, uint64_t counters[DCN_N_STATS]);
+
+/* The same merge ACROSS PROCESSES (one process per GPU, reads sharded, index replicated): an RCCL all-reduce(sum) of the
+ * six u64 words, the path's only collective -- 48 bytes, once per run.  For a host that is not Python (which reduces them
+ * with torch.distributed over RCCL): rank 0 makes an id with dcn_comm_unique_id and hands its 128 bytes to the other ranks
+ * by any means of its own (a file, a socket, MPI, the job launcher); every rank then calls dcn_comm_create -- a collective
+ * call: it returns when all world_size ranks are in it -- and, at the end of its share of the input,
+ * dcn_stats_allreduce_rccl with its contexts (summed on the host first, as dcn_stats_allreduce does).  Every rank gets the
+ * job's totals.  RCCL is bound at first use (dlopen librccl.so.1; DCN_RCCL_LIB names another file): dcn_comm_available
+ * says whether it can be, without touching a GPU.  The reference's counterpart is the mutex-guarded merge of its
+ * worker threads' ProcessingStats (src/local_filter.rs:388-396); it has no multi-process form. */
+#define DCN_COMM_ID_BYTES 128
+typedef struct dcn_comm dcn_comm;
+int dcn_comm_available(void);
+int dcn_comm_unique_id(uint8_t id[DCN_COMM_ID_BYTES]);
+int dcn_comm_create(const uint8_t id[DCN_COMM_ID_BYTES], int world_size, int rank, int device, dcn_comm **out);
+int dcn_stats_allreduce_rccl(dcn_comm *comm, dcn_ctx *const *ctxs, int n_ctx, uint64_t counters[DCN_N_STATS]);
+void dcn_comm_destroy(dcn_comm *comm);
 
 /* ---- measurement ------------------------------------------------------------------------------------ */
 

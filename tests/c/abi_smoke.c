@@ -44,6 +44,28 @@ int main(void) {
     if (dcn_set_minimizer_variant(7, 32, 1) != DCN_OK || dcn_get_minimizer_variant(&rot, &bits, &comb) != DCN_OK ||
         rot != 7 || bits != 32 || comb != 1 || dcn_set_minimizer_variant(1, 16, 0) != DCN_OK)
         return 12;
+    /* ABI version: a binding refuses a library of another major */
+    uint32_t major = 0, minor = 0;
+    if (dcn_abi_version(&major, &minor) != DCN_OK || major != DCN_ABI_MAJOR || minor < DCN_ABI_MINOR) return 14;
+    if (dcn_abi_version(NULL, &minor) != DCN_ERR_ARG) return 15;
+    /* a non-default rule refuses windows its generic kernel cannot hold, when the index is made (not at the first filter call) */
+    if (dcn_set_minimizer_variant(7, 16, 0) != DCN_OK) return 16;
+    {
+        const uint64_t one_key = 1;
+        rc = dcn_index_from_keys(&one_key, 1, 31, 201, 0, &idx);
+        if (rc != DCN_ERR_ARG || idx != NULL || strstr(dcn_last_error(), "w <= 128") == NULL) return 17;
+    }
+    if (dcn_set_minimizer_variant(1, 16, 0) != DCN_OK) return 18;
+    /* the RCCL communicator: argument errors without touching a GPU */
+    {
+        dcn_comm *comm = NULL;
+        uint8_t id[DCN_COMM_ID_BYTES];
+        uint64_t counters[DCN_N_STATS];
+        memset(id, 0, sizeof id);
+        if (dcn_comm_create(NULL, 1, 0, 0, &comm) != DCN_ERR_ARG || dcn_comm_create(id, 2, 2, 0, &comm) != DCN_ERR_ARG || comm != NULL) return 19;
+        if (dcn_comm_unique_id(NULL) != DCN_ERR_ARG || dcn_stats_allreduce_rccl(NULL, NULL, 0, counters) != DCN_ERR_ARG) return 20;
+        dcn_comm_destroy(NULL);
+    }
     double rate = -1.0;
     if (dcn_index_probe_ceiling(NULL, NULL, 10, 1, &rate) != DCN_ERR_ARG) return 13;
     printf("%s devices=%d rc=%d\n", v, ndev, rc);

@@ -135,7 +135,7 @@ def _rust_of_c(ctype):
     t = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*\s*\[[^\]]*\]\s*$", "*", ctype.strip())  # `name[N]` parameter = pointer
     toks = re.findall(r"const|\*|[A-Za-z_][A-Za-z0-9_]*", t)
     base = {"uint8_t": "u8", "uint32_t": "u32", "uint64_t": "u64", "int": "c_int", "char": "c_char", "void": "c_void",
-            "float": "f32", "double": "f64", "dcn_index": "dcn_index", "dcn_ctx": "dcn_ctx", "dcn_params": "dcn_params"}
+            "float": "f32", "double": "f64", "dcn_index": "dcn_index", "dcn_ctx": "dcn_ctx", "dcn_params": "dcn_params", "dcn_comm": "dcn_comm"}
     # drop a trailing parameter name (an identifier that is not a known type word, after the type is complete)
     while toks and toks[-1] not in base and toks[-1] not in ("const", "*"):
         toks.pop()

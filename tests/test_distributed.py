@@ -56,6 +56,39 @@ def test_two_ranks_with_the_gpu_engine(tmp_path):
     assert res["world"] == 2 and res["stats"] == res["want"] and res["keep_equal"]
 
 
+@pytest.mark.gpu
+def test_rccl_communicator_of_the_c_abi_on_one_rank(dcn, oracle):
+    """dcn_comm_* / dcn_stats_allreduce_rccl (what a host that is not Python reduces the six counters with): a
+    world of ONE rank on the one GPU of the box -- RCCL is really loaded, a communicator really made, the all-reduce
+    really run on its stream; with one rank the sum over ranks is the host sum over this process's contexts.  (More
+    ranks need more devices: RCCL refuses two ranks on one GPU.  bench.py runs it beside torch's all-reduce at N > 1.)"""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(40, 300)))) for _ in range(500)]
+    idx = dcn.Index.from_keys(np.array([1, 2, 3], np.uint64), 31, 15)
+    procs = [dcn.FilterProcessor(idx, max_batch_bases=1 << 20, max_batch_reads=1 << 10) for _ in range(2)]
+    b, o = oracle.concat_reads(reads)
+    procs[0].filter_batch(b, o)
+    procs[1].filter_batch(b, o)
+    procs[1].filter_batch(b, o)
+    handed = []
+
+    def exchange(raw):
+        handed.append(raw)
+        return raw
+    comm = dcn.distributed.Comm(1, 0, 0, exchange)
+    assert len(handed[0]) == 128 and any(handed[0])
+    got = comm.allreduce_counters(procs)
+    one = procs[0].stats()
+    assert got["total_seqs"] == 3 * len(reads) and got["total_bp"] == 3 * len(b)
+    assert got == {n: 3 * one[n] for n in one}
+    assert comm.allreduce_counters([]) == {n: 0 for n in one}          # a rank that had no batches
+    comm.close()
+    for p in procs:
+        p.close()
+    idx.close()
+
+
 def _fake_sysfs(root, gpus):
     """gpus: [(numa, cpulist text)] -> a sysfs tree with one CPU-only KFD node followed by the GPU nodes"""
     nodes = root / "class/kfd/kfd/topology/nodes"

@@ -368,3 +368,46 @@ def test_index_clone_and_stats_allreduce(oracle, dcn, genome, index_pair):
     assert tot["output_seq_counter"] == int(want[0].sum())
     with pytest.raises(dcn.DeaconHipError):
         gidx.clone(99)
+
+
+def test_contexts_on_several_threads_pack_side_by_side(oracle, dcn, genome, index_pair, monkeypatch):
+    """Round 4: the host pool runs the jobs of several contexts at a time.  Three contexts, each on its
+    own thread, each filtering its own pageable batches cut into dozens of chunks (so their packing jobs interleave on the
+    shared workers) -- every call must give the oracle's results, as the same calls do one after another."""
+    import threading
+    small_chunks(monkeypatch)
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(77)
+    jobs = []
+    for t in range(3):
+        batches = []
+        for _ in range(4):
+            reads = mixed_reads(rng, genome, n_short=1500, n_long=4)
+            b, o = oracle.concat_reads(reads)
+            uid = None if t != 1 else (np.arange(len(reads)) // 2).astype(np.uint32)
+            batches.append((b, o, uid))
+        jobs.append(batches)
+    procs = [dcn.FilterProcessor(gidx, deplete=(t == 2), max_batch_bases=1 << 21, max_batch_reads=1 << 13) for t in range(3)]
+    want = [[oracle_batch(oracle, oidx, procs[t], *bt) for bt in jobs[t]] for t in range(3)]
+    got, errors = [[None] * 4 for _ in range(3)], []
+
+    def work(t):
+        try:
+            for rep in range(3):
+                for i, (b, o, uid) in enumerate(jobs[t]):
+                    got[t][i] = procs[t].filter_batch(b, o, uid)
+        except Exception as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+        assert not th.is_alive()
+    assert not errors, errors
+    for t in range(3):
+        for i in range(4):
+            assert_same(got[t][i], want[t][i])
+    for p in procs:
+        p.close()

@@ -61,3 +61,34 @@ def test_pack_ascii_threaded_path_and_codes(dcn):
     p, m = dcn.pack_ascii(b"ACTGacgtN")
     assert [(int(p[0]) >> (2 * i)) & 3 for i in range(9)] == [0, 1, 2, 3, 0, 1, 3, 2, 3]
     assert int(m[0]) == 1 << 8
+
+
+def test_callers_on_several_threads_share_the_host_pool(dcn):
+    """Round 4: the pool runs several jobs at a time (the contexts of one process pack side by side): six caller threads,
+    each packing its own inputs of its own sizes over and over through the shared workers, must each get exactly the
+    single-threaded answer every time -- a slice run twice, skipped, or run with a neighbour's arguments shows here."""
+    import threading
+    rng = np.random.default_rng(11)
+    alpha = np.frombuffer(b"ACGTN", np.uint8)
+    inputs = [alpha[rng.integers(0, 5, n)] for n in (5_000_000, 4_200_001, 37, 3_000_003, 4_194_304, 6_100_000)]
+    want = [numpy_pack(b) for b in inputs]
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(12):
+                b = inputs[(t + it) % len(inputs)]
+                p, m = dcn.pack_ascii(b)
+                wp, wm = want[(t + it) % len(inputs)]
+                if not (np.array_equal(p, wp) and np.array_equal(m, wm)):
+                    errors.append((t, it, "differs"))
+        except Exception as ex:  # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+        assert not th.is_alive(), "a caller never got its job back from the pool"
+    assert not errors, errors

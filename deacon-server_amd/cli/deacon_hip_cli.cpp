@@ -1568,27 +1568,61 @@ void debug_lines(deacon::FilterProcessor &proc, const deacon::Index &index, cons
         return;
     }
     const uint32_t n_reads = (uint32_t)b.recs.size();
-    const unsigned k = index.header().kmer_length;
-    std::vector<uint64_t> off(n_reads + 1), hashes(b.bases.size() + 1);
-    std::vector<uint32_t> pos(b.bases.size() + 1);
-    deacon::check(dcn_minimizer_hashes_batch(proc.raw(), b.bases.data(), b.offsets.data(), n_reads, prefix_length, off.data(),
-                                             hashes.data(), pos.data(), hashes.size()));
-    hashes.resize(off[n_reads]);
-    std::vector<bool> member = index.contains(hashes);
+    const unsigned k = index.header().kmer_length, w = index.header().window_size;
     std::string kmers;
     std::vector<uint64_t> seen;
-    for (uint32_t i = 0; i < n_reads; ++i) {
+    auto line = [&](uint32_t i, const uint64_t *hs, const bool *in_set, size_t n, auto pos_of) {
         const Rec &r = b.recs[i];
         kmers.clear();
         seen.clear();
-        for (uint64_t j = off[i]; j < off[i + 1]; ++j) {
-            if (!member[j] || std::find(seen.begin(), seen.end(), hashes[j]) != seen.end()) continue;
-            seen.push_back(hashes[j]);
+        for (size_t j = 0; j < n; ++j) {
+            if (!in_set[j] || std::find(seen.begin(), seen.end(), hs[j]) != seen.end()) continue;
+            seen.push_back(hs[j]);
             if (!kmers.empty()) kmers += ',';
-            kmers.append(reinterpret_cast<const char *>(b.bases.data()) + r.seq_off + pos[j], k);
+            kmers.append(reinterpret_cast<const char *>(b.bases.data()) + r.seq_off + pos_of(j), k);
         }
         std::fprintf(stderr, "DEBUG: %.*s hits=%u/%u keep=%s kmers=[%s]\n", (int)r.id_len, chars + r.id_off, b.hits[i],
                      b.total[i], b.keep[i] ? "true" : "false", kmers.c_str());
+    };
+    // calls that fit the context; a read longer than any call goes piece by piece (deacon::append_minimizer_hashes_any_length)
+    const uint64_t cap_bases = proc.config().max_batch_bases, cap_reads = proc.config().max_batch_reads;
+    std::vector<uint64_t> off, hashes, sub, pos64;
+    std::vector<uint32_t> pos;
+    std::unique_ptr<bool[]> member;
+    auto members_of = [&](const std::vector<uint64_t> &hs) {
+        std::vector<bool> m = index.contains(hs);
+        member.reset(new bool[std::max<size_t>(m.size(), 1)]);
+        for (size_t j = 0; j < m.size(); ++j) member[j] = m[j];
+    };
+    for (uint32_t r0 = 0; r0 < n_reads;) {
+        uint32_t r1 = r0;
+        while (r1 < n_reads && r1 - r0 < cap_reads && b.offsets[r1 + 1] - b.offsets[r0] <= cap_bases) ++r1;
+        if (r1 == r0) {
+            hashes.clear();
+            pos64.clear();
+            const Rec &r = b.recs[r0];
+            deacon::append_minimizer_hashes_any_length(proc, b.bases.data() + r.seq_off, r.seq_len, k, w, prefix_length,
+                                                       std::max<uint64_t>(cap_bases / 2, 64), hashes, &pos64);
+            members_of(hashes);
+            line(r0, hashes.data(), member.get(), hashes.size(), [&](size_t j) { return pos64[j]; });
+            ++r0;
+            continue;
+        }
+        const uint64_t nb = b.offsets[r1] - b.offsets[r0];
+        sub.resize(r1 - r0 + 1);
+        for (uint32_t r = r0; r <= r1; ++r) sub[r - r0] = b.offsets[r] - b.offsets[r0];
+        off.assign(r1 - r0 + 1, 0);
+        hashes.resize(nb + 1);
+        pos.resize(nb + 1);
+        deacon::check(dcn_minimizer_hashes_batch(proc.raw(), b.bases.data() + b.offsets[r0], sub.data(), r1 - r0, prefix_length, off.data(),
+                                                 hashes.data(), pos.data(), hashes.size()));
+        hashes.resize(off[r1 - r0]);
+        members_of(hashes);
+        for (uint32_t i = r0; i < r1; ++i) {
+            const uint64_t a0 = off[i - r0];
+            line(i, hashes.data() + a0, member.get() + a0, off[i - r0 + 1] - a0, [&](size_t j) { return (uint64_t)pos[a0 + j]; });
+        }
+        r0 = r1;
     }
 }
 
@@ -1697,6 +1731,8 @@ int run_filter(const FilterArgs &a) {
     cfg.max_batch_reads = batch_reads + 2;
     if (const char *e = std::getenv("DCN_CLI_MAX_BATCH_READS"))  // test hook: force batches to be cut into several calls
         cfg.max_batch_reads = (uint32_t)std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("DCN_CLI_MAX_BATCH_BASES"))  // test hook: records longer than a call at test sizes
+        cfg.max_batch_bases = (uint64_t)std::max(1024, std::atoi(e));
 
     // ---- stage 1: parsed batches, in input order --------------------------------------------------------------
     // plain regular file, single input: mmap + parallel parsing of record-aligned chunks; otherwise (stdin, gzip,
@@ -1953,6 +1989,40 @@ int run_filter(const FilterArgs &a) {
     }
     m_ctx = std::chrono::duration<double>(clock::now() - start).count();
     Queue<std::unique_ptr<Batch>> submitted(2 * a.devices.size() + 2);
+    // A unit (record, or pair of records) longer than the largest call.  The reference takes records of any length
+    // (src/local_filter.rs:346-374); here the unit's minimizer hashes are collected piece by piece by the same kernels
+    // (deacon::append_minimizer_hashes_any_length: pieces overlapping by one window, the seam's duplicate removed on the GPU's
+    // own say-so), mate 1 then mate 2 (src/filter_common.rs:312-348), and the unit is decided ONCE over all of them by
+    // dcn_should_keep_hashes -- the shape of the server seam (src/remote_filter.rs:230-301).  Runs on the feeder thread with
+    // a context of its own; the ordinary calls of the batch go on beside it.
+    std::unique_ptr<deacon::FilterProcessor> giant_proc;
+    uint64_t giant_piece = 1ull << 25;  // bases per piece
+    if (const char *e = std::getenv("DCN_CLI_GIANT_PIECE")) giant_piece = (uint64_t)std::max(64, std::atoi(e));  // test hook
+    auto giant_unit = [&](Batch &b, size_t r0, size_t per) {
+        if (!giant_proc) {
+            deacon::FilterConfig gc = cfg;
+            gc.max_batch_bases = giant_piece + 2 * (hd.kmer_length + hd.window_size) + 64;
+            gc.max_batch_reads = 16;
+            giant_proc.reset(new deacon::FilterProcessor(index, gc));
+        }
+        std::vector<uint64_t> hashes;
+        for (size_t m = 0; m < per; ++m) {
+            const Rec &r = b.recs[r0 + m];
+            deacon::append_minimizer_hashes_any_length(*giant_proc, reinterpret_cast<const uint8_t *>(b.seq_ptr(r)), r.seq_len, hd.kmer_length,
+                                                       hd.window_size, a.prefix_length, giant_piece - (hd.kmer_length + hd.window_size), hashes);
+        }
+        const uint64_t hoff[2] = {0, hashes.size()};
+        dcn_params p = giant_proc->params();
+        uint8_t keep = 0;
+        uint32_t hits = 0, total = 0;
+        deacon::check(dcn_should_keep_hashes(giant_proc->raw(), hashes.data(), hoff, 1, &p, &keep, &hits, &total));
+        const size_t u = r0 / per;
+        b.keep[u] = keep;
+        if (a.debug) {
+            b.hits[u] = hits;
+            b.total[u] = total;
+        }
+    };
     auto submit_batch = [&](Batch &b) {
         b.gpu_seqs.clear();
         b.sub_off.clear();
@@ -1972,7 +2042,11 @@ int run_filter(const FilterArgs &a) {
             size_t r1 = r0;
             while (r1 < n && (r1 - r0) + per <= cfg.max_batch_reads && b.offsets[r1 + per] - b.offsets[r0] <= cfg.max_batch_bases)
                 r1 += per;
-            if (r1 == r0) die("a single record is longer than the largest batch (" + std::to_string(cfg.max_batch_bases) + " bases)");
+            if (r1 == r0) {  // a unit no call can hold (a chromosome among the reads): see giant_unit
+                giant_unit(b, r0, per);
+                r0 += per;
+                continue;
+            }
             const size_t u0 = r0 / per;
             deacon::MultiGpuFilter::Job job;
             if (b.seq_in_chars) {

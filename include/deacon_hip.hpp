@@ -20,9 +20,11 @@
 #ifndef DEACON_HIP_HPP
 #define DEACON_HIP_HPP
 
+#include <algorithm>
 #include <array>
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <map>
 #include <memory>
@@ -432,6 +434,53 @@ inline std::pair<std::vector<uint64_t>, std::vector<uint32_t>> get_minimizer_has
     h.resize(out_off[1]);
     p.resize(out_off[1]);
     return {std::move(h), std::move(p)};
+}
+
+// The same for a read of ANY length -- longer than the context's largest batch included (the reference has no such limit:
+// src/local_filter.rs:346-374 takes whatever paraseq hands it, whole chromosomes too).  A window's choice depends only on
+// its own l = k + w - 1 bases, so the read is cut into pieces of `piece_windows` windows, each piece one call of
+// dcn_minimizer_hashes_batch; only the rule that drops CONSECUTIVE duplicate positions crosses a seam.  A later piece
+// therefore starts one window early (the last window of its predecessor): that "carry" window's choice c is the last entry
+// of the predecessor's list and the first of this piece's, and the read's list is the lists joined with that first entry
+// removed.  After the ACGT filter (src/filter_common.rs:275-286) c is present in both lists or in neither; which, the GPU
+// says itself: the carry window's l bases travel as a read of their own in the same call and yield one entry or none.
+// Positions are read-relative, as u64 (a chromosome's do not fit the u32 of the per-read call).  Nothing is computed here:
+// every hash and position comes out of the library's kernels.
+inline void append_minimizer_hashes_any_length(FilterProcessor &proc, const uint8_t *seq, uint64_t len, unsigned k, unsigned w,
+                                               uint64_t prefix_length, uint64_t piece_windows, std::vector<uint64_t> &hashes,
+                                               std::vector<uint64_t> *positions = nullptr) {
+    if (len < k) return;                                        // filter_common.rs:217-219, on the full read
+    uint64_t n = (prefix_length > 0 && len > prefix_length) ? prefix_length : len;  // :221-226
+    const uint64_t l = static_cast<uint64_t>(k) + w - 1;
+    if (n < l) return;                                          // no window at all
+    const uint64_t windows = n - l + 1;
+    if (piece_windows < 2) piece_windows = 2;
+    std::vector<uint8_t> buf;
+    std::vector<uint64_t> h;
+    std::vector<uint32_t> p;
+    for (uint64_t s = 0; s < windows; s += piece_windows) {
+        const uint64_t e = std::min(windows, s + piece_windows);
+        const uint64_t first = s ? s - 1 : 0;                    // first window of the piece: the carry window for s > 0
+        const uint64_t piece_len = (e - first) + l - 1;
+        uint64_t offsets[3] = {0, s ? l : 0, (s ? l : 0) + piece_len}, out_off[3] = {0, 0, 0};
+        buf.resize(offsets[2]);
+        if (s) std::memcpy(buf.data(), seq + first, l);          // read 0: the carry window alone (empty for the first piece)
+        std::memcpy(buf.data() + offsets[1], seq + first, piece_len);
+        h.resize(piece_len + 2);
+        p.resize(piece_len + 2);
+        check(dcn_minimizer_hashes_batch(proc.raw(), buf.data(), offsets, 2, 0, out_off, h.data(), p.data(), h.size()));
+        uint64_t from = out_off[1];
+        if (s && out_off[1] == 1) {                              // the carry window's choice passed the ACGT filter:
+            if (out_off[2] == out_off[1] || h[from] != h[0] || p[from] != p[0])
+                throw std::runtime_error("a piece does not start with its carry window's minimizer");
+            ++from;                                              // ... it is the predecessor's last entry, not a new one
+        } else if (s && out_off[1] != 0) {
+            throw std::runtime_error("one window gave more than one minimizer");
+        }
+        hashes.insert(hashes.end(), h.begin() + from, h.begin() + out_off[2]);
+        if (positions)
+            for (uint64_t j = from; j < out_off[2]; ++j) positions->push_back(first + p[j]);
+    }
 }
 
 namespace detail {

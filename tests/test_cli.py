@@ -436,6 +436,132 @@ def test_batches_cut_into_several_calls(tmp_path, oracle, paired, monkeypatch):
     assert [l for l in lines[0::4] if l] == [f"@{i + 1}" for i in range(len(want))]  # --rename numbers across calls
 
 
+def _long_and_short_records(rng, genome, n_short=400):
+    """records of every kind a piecewise scan has to get right: host-derived and random, N runs and scattered N (k-mers that
+    fail the ACGT test on and around piece seams), homopolymers and short-period repeats (ties: the same position chosen
+    by consecutive windows across a seam, positions that re-appear), lengths around the piece size"""
+    recs = []
+    for ln in (70_000, 23_000, 3_001, 2_999, 6_044, 6_045, 6_046, 45_000):
+        s = int(rng.integers(0, len(genome) - ln))
+        recs.append(mutate(rng, genome[s:s + ln], 0.03))
+    r = bytearray(random_reads(rng, 1, 40_000, 40_000, p_n=0.02)[0])        # an N every 50 bases: hardly a clean window
+    recs.append(bytes(r))
+    r = bytearray(mutate(rng, genome[1000:31_000], 0.01))
+    r[2_900:3_100] = b"N" * 200                                              # an N run across the first seam
+    r[8_990:9_010] = b"n" * 20
+    recs.append(bytes(r))
+    recs.append(b"A" * 9_000 + genome[500:4_000] + b"AC" * 4_000 + b"ACGT" * 2_500 + genome[7_000:9_000])
+    recs.append((b"ACGTTGCA" * 3 + b"N") * 1_500)
+    for _ in range(n_short):
+        ln = int(rng.integers(25, 400))
+        s = int(rng.integers(0, len(genome) - ln))
+        recs.append(mutate(rng, genome[s:s + ln], 0.02) if rng.random() < 0.5 else random_reads(rng, 1, ln, ln, p_n=0.01)[0])
+    order = rng.permutation(len(recs))
+    return [recs[i] for i in order]
+
+
+@gpu
+@pytest.mark.parametrize("mode", ["search", "deplete", "prefix", "paired"])
+def test_records_longer_than_the_largest_call(tmp_path, oracle, monkeypatch, mode):
+    """the reference takes records of any length (src/local_filter.rs:346-374).  With the largest call
+    shrunk to 20 kbp and pieces of 3 kbp, a dozen records go piece by piece -- dozens of seams each, on N runs, ties and
+    repeats -- among ordinary reads; kept records == the oracle's decisions on the whole records."""
+    rng = np.random.default_rng(61)
+    genome = random_reads(rng, 1, 80_000, 80_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    oidx = oracle.Index.build([genome])
+    recs = _long_and_short_records(rng, genome)
+    if len(recs) % 2:
+        recs.pop()
+    monkeypatch.setenv("DCN_CLI_MAX_BATCH_BASES", "20000")
+    monkeypatch.setenv("DCN_CLI_GIANT_PIECE", "3000")
+    b, o = oracle.concat_reads(recs)
+    flags = {"search": ["-a", 2, "-r", 0.01], "deplete": ["-d", "-a", 1, "-r", 0.02], "prefix": ["-p", 7000, "-r", 0.05], "paired": ["-d"]}[mode]
+    kw = {"search": dict(abs_threshold=2, rel_threshold=0.01), "deplete": dict(abs_threshold=1, rel_threshold=0.02, deplete=True),
+          "prefix": dict(rel_threshold=0.05, prefix_length=7000), "paired": dict(deplete=True)}[mode]
+    if mode == "paired":
+        fasta(tmp_path / "r1.fa", [(f"r{i}/1", recs[2 * i].decode()) for i in range(len(recs) // 2)])
+        fasta(tmp_path / "r2.fa", [(f"r{i}/2", recs[2 * i + 1].decode()) for i in range(len(recs) // 2)])
+        out = run("filter", *flags, idx, tmp_path / "r1.fa", tmp_path / "r2.fa").stdout.decode()
+        keep, _, _ = oracle.filter_batch(oidx, b, o, (np.arange(len(recs)) // 2).astype(np.uint32), **kw)
+        want = [f"r{i}/{m}" for i in range(len(recs) // 2) if keep[i] for m in (1, 2)]
+    else:
+        # 70-column FASTA: the long records are multi-line
+        (tmp_path / "r.fa").write_bytes(b"".join(b">r%d\n" % i + b"\n".join(r[j:j + 70] for j in range(0, len(r), 70)) + b"\n"
+                                                 for i, r in enumerate(recs)))
+        out = run("filter", *flags, idx, tmp_path / "r.fa").stdout.decode()
+        keep, _, _ = oracle.filter_batch(oidx, b, o, **kw)
+        want = [f"r{i}" for i in range(len(recs)) if keep[i]]
+    got = [l[1:] for l in out.split("\n") if l.startswith(">")]
+    assert got == want and 0 < len(want) < len(recs)
+
+
+@gpu
+def test_debug_lines_of_a_record_longer_than_the_largest_call(tmp_path, oracle, monkeypatch):
+    """--debug lists the k-mers of the hits (src/local_filter.rs:354-363): for a record that goes piece by piece the
+    positions come back read-relative across the seams"""
+    rng = np.random.default_rng(62)
+    genome = random_reads(rng, 1, 30_000, 30_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    oidx = oracle.Index.build([genome])
+    keys = set(int(x) for x in oidx.keys())
+    r = bytearray(random_reads(rng, 1, 26_000, 26_000)[0])
+    r[5_000:5_400] = genome[100:500]
+    r[11_950:12_100] = genome[9_000:9_150]        # a hit region across a seam of 6 kbp pieces
+    r[20_000:20_200] = genome[100:300]            # the same k-mers again: listed once
+    reads = [bytes(r), genome[2_000:2_150], random_reads(rng, 1, 120, 120)[0]]
+    fastq(tmp_path / "r.fq", [(f"r{i}", x.decode()) for i, x in enumerate(reads)])
+    monkeypatch.setenv("DCN_CLI_MAX_BATCH_BASES", "12000")
+    monkeypatch.setenv("DCN_CLI_GIANT_PIECE", "6000")
+    err = run("filter", idx, tmp_path / "r.fq", "--debug").stderr.decode().splitlines()
+    lines = [l for l in err if l.startswith("DEBUG: ")]
+    assert len(lines) == 3
+    for i, x in enumerate(reads):
+        h, p = oracle.minimizer_hashes_and_positions(x, 31, 15)
+        seen, kmers = set(), []
+        for hv, pv in zip(h.tolist(), p.tolist()):
+            if hv in keys and hv not in seen:
+                seen.add(hv)
+                kmers.append(x[pv:pv + 31].decode())
+        keep = oracle.meets_filtering_criteria(len(seen), len(h), 2, 0.01, False)
+        assert lines[i] == f"DEBUG: r{i} hits={len(seen)}/{len(h)} keep={'true' if keep else 'false'} kmers=[{','.join(kmers)}]", i
+    assert lines[0].count(",") > 20
+
+
+@gpu
+def test_a_300_mbp_record_among_short_reads(tmp_path, oracle):
+    """the shape VERDICT r3 names: a chromosome-sized FASTA record (300 Mbp, far beyond the 84 Mbp of the largest call) in a
+    file of short reads, -a 2 -r 0.01 and -d, default batch sizes; keep == the oracle's decision on the whole record"""
+    rng = np.random.default_rng(63)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    genome = alpha[rng.integers(0, 4, 2_000_000)].tobytes()
+    idx = build_index(tmp_path, [("g", genome)], name="g2m") if False else None
+    (tmp_path / "g.fa").write_bytes(b">g\n" + genome + b"\n")
+    idx = tmp_path / "g.idx"
+    run("index", "build", tmp_path / "g.fa", "-o", idx, "-q")
+    oidx = oracle.Index.build([genome])
+    big = alpha[rng.integers(0, 4, 300_000_000)]
+    big[150_000_000:150_400_000] = np.frombuffer(genome[:400_000], np.uint8)     # 0.13 % of it from the index: ~0.3 % of its minimizers
+    big[33_554_000:33_555_000] = ord("N")                                          # an N run where the first seam falls
+    big = big.tobytes()
+    shorts = [genome[s:s + 150] for s in range(0, 3000, 150)] + random_reads(rng, 20, 150, 150)
+    recs = shorts[:25] + [big] + shorts[25:]
+    with open(tmp_path / "r.fa", "wb") as f:
+        for i, r in enumerate(recs):
+            f.write(b">r%d\n" % i + r + b"\n")
+    b, o = oracle.concat_reads(recs)
+    for flags, kw in ((["-a", 2, "-r", 0.01], dict(abs_threshold=2, rel_threshold=0.01)), (["-d"], dict(deplete=True))):
+        keep, hits, total = oracle.filter_batch(oidx, b, o, threads=8, **kw)
+        out = tmp_path / "out.fa"
+        summ = tmp_path / "s.json"
+        run("filter", *flags, idx, tmp_path / "r.fa", "-o", out, "-s", summ)
+        got = [l[1:].decode() for l in open(out, "rb") if l.startswith(b">")]
+        assert got == [f"r{i}" for i in range(len(recs)) if keep[i]]
+        s = json.loads(summ.read_text())
+        assert s["seqs_in"] == len(recs) and s["bp_in"] == len(b)
+    assert int(total[25]) > 30_000_000 and int(hits[25]) > 10_000 and not keep[25]      # (the last run was -d: a match is dropped)
+
+
 @gpu
 @pytest.mark.parametrize("paired", [False, True])
 def test_multi_gpu_driver_gives_the_single_context_output(tmp_path, oracle, paired, monkeypatch):

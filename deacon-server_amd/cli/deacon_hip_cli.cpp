@@ -1544,7 +1544,8 @@ struct FilterArgs {
     double rel_threshold = 0.01;
     size_t prefix_length = 0;
     bool deplete = false, rename = false, debug = false, quiet = false;
-    size_t threads = 8;
+    size_t threads = 8;          // the reference's default (src/main.rs:68) ...
+    bool threads_given = false;  // ... which, when -t is not given, grows to three quarters of the CPUs the process may use
     int compression_level = 2;
     std::vector<int> devices{0};  // --gpus N / --devices a,b,...: one pipeline context per entry (repeats allowed)
 };
@@ -1654,7 +1655,14 @@ size_t usable_cpus() {
 }
 
 // ---- deacon filter (src/local_filter.rs:575-824) ---------------------------------------------------------------
-int run_filter(const FilterArgs &a) {
+int run_filter(const FilterArgs &a_in) {
+    // -t counts the reference's filter workers (default 8); here the filtering is the GPU's and the host threads parse and
+    // format around it, a job that profits from more of them up to about three quarters of the CPUs (the library's packers
+    // and the runtime want the rest: -t 12 beat -t 8 and -t 16 on a 16-CPU share, profiles/r03 cli notes).  An explicit -t
+    // is taken as given.
+    FilterArgs a_eff = a_in;
+    if (!a_eff.threads_given) a_eff.threads = std::max<size_t>(a_eff.threads, std::min<size_t>(usable_cpus() * 3 / 4, 32));
+    const FilterArgs &a = a_eff;
     StageClock t_parse, t_gpu, t_gpu_wait, t_format, t_write, t_push_wait;
     double m_index = 0, m_ctx = 0, m_feeder_done = 0, m_gpu_done = 0, m_written = 0;  // milestones, seconds since start
     const bool cli_timing = std::getenv("DCN_CLI_TIMING") != nullptr;
@@ -2388,7 +2396,7 @@ int main(int argc, char **argv) {
                 else if (s == "-d" || s == "--deplete") a.deplete = true;
                 else if (s == "-R" || s == "--rename") a.rename = true;
                 else if (s == "-s" || s == "--summary") a.summary = need(++i), a.has_summary = true;
-                else if (s == "-t" || s == "--threads") a.threads = (size_t)std::atoll(need(++i).c_str());
+                else if (s == "-t" || s == "--threads") a.threads = (size_t)std::atoll(need(++i).c_str()), a.threads_given = true;
                 else if (s == "--compression-level") a.compression_level = std::atoi(need(++i).c_str());
                 else if (s == "--debug") a.debug = true;
                 else if (s == "-q" || s == "--quiet") a.quiet = true;

@@ -152,6 +152,9 @@ template <int N>
 struct IntTag {
     static constexpr int value = N;
 };
+#ifndef DCN_EXPORT_UNIFORM
+#define DCN_EXPORT_UNIFORM 0 // 1: rounds whose exported hits all belong to one unit skip the run-head bookkeeping (A/B: profiles/r04_ab.txt)
+#endif
 #ifndef DCN_PIPE_B
 #define DCN_PIPE_B 0 // 1: phase B software-pipelined by one round (the next round's owner search and sequence / mask loads
                      // are issued between this round's set probe and its use); needs DCN_U_FINAL == 1
@@ -573,6 +576,28 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
                 {
                     const bool rec = hit[u] && !lok;
                     const unsigned long long rb = (DCN_EXP & 256) ? 0ull : __ballot(rec);
+#if DCN_EXPORT_UNIFORM
+                    // Long reads: a wave's tiles belong to one to three units and items are in flat order, so nearly every
+                    // round's hits are one unit's.  Then the run bookkeeping (a shuffle, a second ballot, the head-lane
+                    // arithmetic) collapses to one popcount: rank among the hit lanes, one length update by the first.
+                    const uint32_t us0 = rb ? (uint32_t)__builtin_amdgcn_readlane((int)o_uslot[u], __ffsll((long long)rb) - 1) : 0u;
+                    const bool one_unit = rb && __ballot(rec && o_uslot[u] != us0) == 0;
+                    if (one_unit) { // wave-uniform
+                        const unsigned long long lt = (1ull << lane) - 1;
+                        any_rec = true;
+                        const uint32_t base = sh.uhits[us0];
+                        if (rec) {
+                            const uint32_t at = base + (uint32_t)__popcll(rb & lt);
+                            if (at < sh.ucap[us0]) {
+                                if (!(DCN_EXP & 512)) a.rec_hash[sh.run_base[us0] + at] = hash[u];
+                            } else {
+                                a.status->run_overflow = 1;
+                            }
+                            if (hash[u] == 0) a.g_zero[sh.unit_of[us0]] = 1;
+                            if ((rb & lt) == 0) sh.uhits[us0] = base + (uint32_t)__popcll(rb); // (its first hit lane, after the reads)
+                        }
+                    } else
+#endif
                     if (rb) { // wave-uniform
                         const unsigned long long lt = (1ull << lane) - 1;
                         const unsigned long long below = rb & lt;

@@ -445,6 +445,7 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
 
     elapsed, counters, stage = timed(True)
     elapsed2, _, stage2 = timed(False)
+    c_abi = c_abi_rccl_check(proc, world, device, coll_device) if world > 1 else None
     proc.close()
     bases_done = sum(batches[i % len(batches)].n_bases for i in range(steps))  # this rank
     total_bp = counters["total_bp"]
@@ -455,6 +456,7 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
     achieved = algo / (scan_ms * 1e-3) / 1e9
     mins = float(np.mean([n_min[i % len(batches)] for i in range(steps)]))
     res = {
+        "c_abi_rccl": c_abi,
         "value": total_bp / elapsed / 1e6, "unit": "Mbp/s", "ms_per_step": elapsed / steps * 1e3,
         "bases_per_batch": int(np.mean([b.n_bases for b in batches])), "reads_per_batch": int(np.mean([b.n_reads for b in batches])),
         "batches_rotated": len(batches),
@@ -478,11 +480,41 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
     return res, counters, elapsed, bases_done
 
 
+def c_abi_rccl_check(proc, world, device, coll_device):
+    """After the timed regions, at N > 1: the same six counters reduced a second time by the C ABI's own RCCL communicator
+    (dcn_comm_* / dcn_stats_allreduce_rccl: what a host that is not Python would call), compared with torch.distributed's
+    all-reduce of them.  Every rank first says whether it can load RCCL at all (a torch collective), so that no rank enters
+    the communicator's collective set-up alone; the id travels by broadcast_object_list.  None when it was not tried."""
+    if os.environ.get("DCN_BENCH_NO_C_ABI_RCCL") or str(coll_device).startswith("cpu"):
+        return None
+    t0 = time.time()
+    try:
+        ok = torch.tensor([1 if dcn._native.lib().dcn_comm_available() == 0 else 0], dtype=torch.int64, device=coll_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            return {"tried": False, "why": "librccl could not be loaded by the library on some rank"}
+
+        def exchange(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = dcn.distributed.Comm(world, dist.get_rank(), device.index or 0, exchange)
+        local = proc.stats()
+        got = comm.allreduce_counters([proc])
+        comm.close()
+        want = dcn.distributed.allreduce_counters(local, device=coll_device)
+        return {"tried": True, "matches_torch_all_reduce": got == want, "total_bp": int(got["total_bp"]), "seconds": time.time() - t0}
+    except Exception as ex:  # never take the bench line with it
+        log(f"C-ABI RCCL check failed: {ex!r}")
+        return {"tried": True, "error": repr(ex)}
+
+
 def committed_traffic(rf, workload, bases_per_batch, index_keys, host_genome):
     """HBM bytes per scan launch from the committed PMC passes of the same workload (profiles/collect_r3.sh ->
     profiles/make_traffic_json.py): counters cannot be read inside a timed run, so `roofline.traffic` is the per-launch
     figure measured for this workload shape on this tree, and says where it comes from."""
-    names = {"short": ("r03_traffic.json", "r02_traffic.json"), "long": ("r03_traffic_long.json",), "mixed": ("r03_traffic_mixed.json",)}
+    names = {"short": ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"), "long": ("r04_traffic_long.json", "r03_traffic_long.json"),
+             "mixed": ("r04_traffic_mixed.json", "r03_traffic_mixed.json")}
     for name in names.get(workload, ()):
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -905,7 +937,7 @@ def compact_line(out):
         c["decisions_only"] = _pick(do, ("value", "ms_per_step", "decisions_identical_to_counting_mode"))
     col = out.get("collective")
     if col:
-        c["collective"] = _pick(col, ("backend", "world_size", "total_bp_all_reduced", "total_bp_expected", "total_bp_matches"))
+        c["collective"] = _pick(col, ("backend", "world_size", "total_bp_all_reduced", "total_bp_expected", "total_bp_matches", "c_abi_rccl_matches"))
     oks = []
 
     def leg(d):
@@ -1132,7 +1164,10 @@ def main():
                   "world_size": dist.get_world_size() if world > 1 else 1,
                   "total_bp_all_reduced": int(counters["total_bp"]), "total_bp_expected": int(t_exp.item()),
                   "total_bp_matches": int(counters["total_bp"]) == int(t_exp.item()),
-                  "cpu_binding": {k_: v for k_, v in binding.items() if k_ != "cpus"} if binding else None}
+                  "cpu_binding": {k_: v for k_, v in binding.items() if k_ != "cpus"} if binding else None,
+                  "c_abi_rccl": head.pop("c_abi_rccl", None)}
+    if collective["c_abi_rccl"] and "matches_torch_all_reduce" in collective["c_abi_rccl"]:
+        collective["c_abi_rccl_matches"] = collective["c_abi_rccl"]["matches_torch_all_reduce"]
     if world > 1:  # every rank's binding, for the record: number of CPUs each rank's host threads may use
         t_b = torch.zeros(world, dtype=torch.int64, device=coll_device)
         t_b[rank] = len((binding or {}).get("cpus") or os.sched_getaffinity(0))

@@ -531,7 +531,7 @@ def test_debug_lines_of_a_record_longer_than_the_largest_call(tmp_path, oracle, 
 @gpu
 def test_a_300_mbp_record_among_short_reads(tmp_path, oracle):
     """the shape VERDICT r3 names: a chromosome-sized FASTA record (300 Mbp, far beyond the 84 Mbp of the largest call) in a
-    file of short reads, -a 2 -r 0.01 and -d, default batch sizes; keep == the oracle's decision on the whole record"""
+    file of short reads, -a 2 -r 0.01, -r 0.001 and -d, default batch sizes; keep == the oracle's decision on the whole record"""
     rng = np.random.default_rng(63)
     alpha = np.frombuffer(b"ACGT", np.uint8)
     genome = alpha[rng.integers(0, 4, 2_000_000)].tobytes()
@@ -549,7 +549,9 @@ def test_a_300_mbp_record_among_short_reads(tmp_path, oracle):
         for i, r in enumerate(recs):
             f.write(b">r%d\n" % i + r + b"\n")
     b, o = oracle.concat_reads(recs)
-    for flags, kw in ((["-a", 2, "-r", 0.01], dict(abs_threshold=2, rel_threshold=0.01)), (["-d"], dict(deplete=True))):
+    # (49,866 of its 37.5 M minimizers hit: no match at the default -r 0.01, which asks for 375 k; a match at -r 0.001)
+    for flags, kw in ((["-a", 2, "-r", 0.01], dict(abs_threshold=2, rel_threshold=0.01)), (["-r", 0.001], dict(rel_threshold=0.001)),
+                      (["-d", "-r", 0.001], dict(deplete=True, rel_threshold=0.001))):
         keep, hits, total = oracle.filter_batch(oidx, b, o, threads=8, **kw)
         out = tmp_path / "out.fa"
         summ = tmp_path / "s.json"
@@ -558,7 +560,7 @@ def test_a_300_mbp_record_among_short_reads(tmp_path, oracle):
         assert got == [f"r{i}" for i in range(len(recs)) if keep[i]]
         s = json.loads(summ.read_text())
         assert s["seqs_in"] == len(recs) and s["bp_in"] == len(b)
-    assert int(total[25]) > 30_000_000 and int(hits[25]) > 10_000 and not keep[25]      # (the last run was -d: a match is dropped)
+    assert int(total[25]) > 30_000_000 and int(hits[25]) > int(total[25]) // 1000 and not keep[25]   # (the last run was -d: the match is dropped)
 
 
 @gpu

@@ -445,7 +445,6 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
 
     elapsed, counters, stage = timed(True)
     elapsed2, _, stage2 = timed(False)
-    c_abi = c_abi_rccl_check(proc, world, device, coll_device) if world > 1 else None
     proc.close()
     bases_done = sum(batches[i % len(batches)].n_bases for i in range(steps))  # this rank
     total_bp = counters["total_bp"]
@@ -456,7 +455,6 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
     achieved = algo / (scan_ms * 1e-3) / 1e9
     mins = float(np.mean([n_min[i % len(batches)] for i in range(steps)]))
     res = {
-        "c_abi_rccl": c_abi,
         "value": total_bp / elapsed / 1e6, "unit": "Mbp/s", "ms_per_step": elapsed / steps * 1e3,
         "bases_per_batch": int(np.mean([b.n_bases for b in batches])), "reads_per_batch": int(np.mean([b.n_reads for b in batches])),
         "batches_rotated": len(batches),
@@ -480,30 +478,59 @@ def run_device_workload(index, batches, params, steps, warmup, world, device, re
     return res, counters, elapsed, bases_done
 
 
-def c_abi_rccl_check(proc, world, device, coll_device):
-    """After the timed regions, at N > 1: the same six counters reduced a second time by the C ABI's own RCCL communicator
-    (dcn_comm_* / dcn_stats_allreduce_rccl: what a host that is not Python would call), compared with torch.distributed's
-    all-reduce of them.  Every rank first says whether it can load RCCL at all (a torch collective), so that no rank enters
-    the communicator's collective set-up alone; the id travels by broadcast_object_list.  None when it was not tried."""
+def c_abi_rccl_check(index, batch, params, world, device, coll_device, timeout_s=90.0):
+    """The LAST thing the ranks do together at N > 1, after everything the line needs has been measured: the six counters of a
+    small run reduced by the C ABI's own RCCL communicator (dcn_comm_* / dcn_stats_allreduce_rccl: what a host that is not
+    Python would call) and compared with torch.distributed's all-reduce of the same counters.  Every rank first says whether it
+    can load RCCL at all (a torch collective), so that no rank enters the communicator's collective set-up alone; the id
+    travels by broadcast_object_list.  The C calls run on a helper thread that is given `timeout_s`: a set-up that never
+    returns costs the line one `timed_out` entry, not the run -- nothing after this depends on any communicator (main() ends
+    the process without further collectives when that happened).  None when it was not tried."""
     if os.environ.get("DCN_BENCH_NO_C_ABI_RCCL") or str(coll_device).startswith("cpu"):
         return None
+    import threading
     t0 = time.time()
     try:
         ok = torch.tensor([1 if dcn._native.lib().dcn_comm_available() == 0 else 0], dtype=torch.int64, device=coll_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             return {"tried": False, "why": "librccl could not be loaded by the library on some rank"}
+        n_reads = min(batch.n_reads, 100_000)
+        n_bases = int(batch.d_offsets[n_reads].item())
+        proc = dcn.FilterProcessor(index, abs_threshold=params["abs"], rel_threshold=params["rel"], deplete=params["deplete"],
+                                   max_batch_bases=n_bases, max_batch_reads=n_reads)
+        keep = torch.zeros(n_reads, dtype=torch.uint8, device=device)
+        proc.filter_batch_device(batch.d_bases.data_ptr(), batch.d_offsets.data_ptr(), n_reads, n_bases, keep.data_ptr(), None, None,
+                                 d_unit_id=None, n_units=n_reads)
+        proc.synchronize()
+        local = proc.stats()
+        want = dcn.distributed.allreduce_counters(local, device=coll_device)
+        result = {}
 
         def exchange(raw):
-            box = [raw]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        comm = dcn.distributed.Comm(world, dist.get_rank(), device.index or 0, exchange)
-        local = proc.stats()
-        got = comm.allreduce_counters([proc])
-        comm.close()
-        want = dcn.distributed.allreduce_counters(local, device=coll_device)
-        return {"tried": True, "matches_torch_all_reduce": got == want, "total_bp": int(got["total_bp"]), "seconds": time.time() - t0}
+            b_ = [raw]
+            dist.broadcast_object_list(b_, src=0)
+            return b_[0]
+
+        def work():
+            try:
+                torch.cuda.set_device(device)
+                comm = dcn.distributed.Comm(world, dist.get_rank(), device.index or 0, exchange)
+                result["got"] = comm.allreduce_counters([proc])
+                comm.close()
+            except Exception as ex:  # noqa: BLE001
+                result["error"] = repr(ex)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            return {"tried": True, "timed_out": True, "seconds": time.time() - t0}
+        proc.close()
+        if "error" in result:
+            return {"tried": True, "error": result["error"]}
+        return {"tried": True, "matches_torch_all_reduce": result["got"] == want, "total_bp": int(result["got"]["total_bp"]),
+                "seconds": time.time() - t0}
     except Exception as ex:  # never take the bench line with it
         log(f"C-ABI RCCL check failed: {ex!r}")
         return {"tried": True, "error": repr(ex)}
@@ -1165,9 +1192,7 @@ def main():
                   "total_bp_all_reduced": int(counters["total_bp"]), "total_bp_expected": int(t_exp.item()),
                   "total_bp_matches": int(counters["total_bp"]) == int(t_exp.item()),
                   "cpu_binding": {k_: v for k_, v in binding.items() if k_ != "cpus"} if binding else None,
-                  "c_abi_rccl": head.pop("c_abi_rccl", None)}
-    if collective["c_abi_rccl"] and "matches_torch_all_reduce" in collective["c_abi_rccl"]:
-        collective["c_abi_rccl_matches"] = collective["c_abi_rccl"]["matches_torch_all_reduce"]
+                  "c_abi_rccl": None}
     if world > 1:  # every rank's binding, for the record: number of CPUs each rank's host threads may use
         t_b = torch.zeros(world, dtype=torch.int64, device=coll_device)
         t_b[rank] = len((binding or {}).get("cpus") or os.sched_getaffinity(0))
@@ -1183,6 +1208,10 @@ def main():
         except Exception as ex:  # every rank fails or none does (same code, same sizes); never take the line with it
             log(f"host_path at N = {world} failed: {ex!r}")
             host_path_all = {"error": repr(ex)}
+    if world > 1 and not args.pmc_child:  # (the last thing the ranks do together: see c_abi_rccl_check)
+        collective["c_abi_rccl"] = c_abi_rccl_check(index, batches[0], params, world, device, coll_device)
+        if collective["c_abi_rccl"] and "matches_torch_all_reduce" in collective["c_abi_rccl"]:
+            collective["c_abi_rccl_matches"] = collective["c_abi_rccl"]["matches_torch_all_reduce"]
     if rank == 0:
         total_bp = counters["total_bp"]
         rf = head["roofline"]
@@ -1423,6 +1452,10 @@ def main():
         out["bench_wall_s"] = time.time() - T0
         emit(out, args.detail)
     if world > 1:
+        if (collective.get("c_abi_rccl") or {}).get("timed_out"):  # a helper thread is still inside RCCL: no further collective,
+            sys.stdout.flush()                                      # no orderly teardown around it
+            sys.stderr.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -177,7 +177,7 @@ def check_gpu_index_side(oracle, dcn, path, tmp_path):
         dcn.set_minimizer_variant(*oracle.DEFAULT_VARIANT)
     f, raw, p, keys = file_of(path, tmp_path)
     idx = dcn.Index.from_file(p)
-    assert (idx.k, idx.w, idx.n_keys) == (f["k"], f["w"], len(keys)) and (np.sort(idx.keys()) == keys).all()
+    assert (idx.kmer_length, idx.window_size, idx.n_keys) == (f["k"], f["w"], len(keys)) and (np.sort(idx.keys()) == keys).all()
     out = tmp_path / "product_written.idx"
     idx.write(str(out))
     idx.close()

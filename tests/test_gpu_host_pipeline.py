@@ -315,7 +315,7 @@ def test_runs_of_the_record_array_grow_when_a_batch_fills_them(oracle, dcn, monk
     b, o = oracle.concat_reads(reads)
     want = oracle.filter_batch(oidx, b, o, None, threads=2)
     assert want[1][0] > 8_000 and want[1][-2] == 1
-    for shift in (None, "0", "3"):
+    for shift in (None, "0", "2", "3"):  # (None: a context of an index with w <= 7 starts with one slot per window by itself)
         if shift is None:
             monkeypatch.delenv("DCN_REC_SHIFT", raising=False)
         else:
@@ -327,7 +327,7 @@ def test_runs_of_the_record_array_grow_when_a_batch_fills_them(oracle, dcn, monk
         assert proc.filter_batch(b, o, counts=False).tolist() == want[0].tolist()
         assert proc.stats()["total_seqs"] == 3 * len(reads)  # an overflowed attempt is not counted
         proc.close()
-    monkeypatch.delenv("DCN_REC_SHIFT", raising=False)
+    monkeypatch.setenv("DCN_REC_SHIFT", "2")  # the geometry contexts of a w >= 8 index start with: the switch-over is under test
     dev = torch.device("cuda:0")
     d_b, d_o = torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int64)).to(dev)
     d_k = torch.zeros(len(reads), dtype=torch.uint8, device=dev)

@@ -391,6 +391,13 @@ struct dcn_ctx {
     const dcn_index *index = nullptr;
     int device = 0;
     hipStream_t stream = nullptr, copy_stream = nullptr, d2h_stream = nullptr;
+    // device-pointer API, pack one batch ahead (ensure_pack_ahead): a second packed stream + mask, the pack kernel's own
+    // status words and stream, and per buffer "packed" / "free again" events
+    hipStream_t pack_stream = nullptr;
+    uint32_t *d_packed_b = nullptr, *d_invmask_b = nullptr;
+    dcn_status *d_pack_status = nullptr; // [2]
+    hipEvent_t pack_done[2] = {}, buf_free[2] = {};
+    int pack_buf = 0, pack_ahead_state = 0; // 0 = not tried yet, 1 = ready, -1 = off (DCN_NO_PACK_AHEAD, or no memory for it)
     static constexpr int N_STAGE = 3, N_EV = 8, N_SLOTS = 2;
     hipEvent_t copy_done = nullptr, stage_free[N_STAGE] = {};
     hipEvent_t ev_h2d[N_EV] = {}, ev_comp[N_EV] = {};
@@ -508,6 +515,17 @@ void free_ctx(dcn_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     if (c->d2h_stream) hipStreamSynchronize(c->d2h_stream);
+    if (c->pack_stream) {
+        hipStreamSynchronize(c->pack_stream);
+        hipStreamDestroy(c->pack_stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->pack_done[i]) hipEventDestroy(c->pack_done[i]);
+        if (c->buf_free[i]) hipEventDestroy(c->buf_free[i]);
+    }
+    if (c->d_packed_b) hipFree(c->d_packed_b);
+    if (c->d_invmask_b) hipFree(c->d_invmask_b);
+    if (c->d_pack_status) hipFree(c->d_pack_status);
     for (auto &sl : c->slots) free_slot_buffers(sl);
     void *dev[] = {c->d_ascii, c->d_offsets, c->d_unit_id, c->d_packed, c->d_invmask,
                    c->d_read_tiles, c->d_read_tile_first, c->d_unit_first_read, c->d_unit_tile_first, c->d_unit_tile_count, c->d_tiles,
@@ -600,8 +618,42 @@ struct BatchView {
     dcn_batch_report *d_report = nullptr;
 };
 
+// Device-pointer API: the pack kernel of batch i+1 runs beside the scan kernel of batch i.  The pack is a streaming kernel
+// (1 B/bp in, 0.375 out: 0.39 ms of a 3.7 ms step at 1.5 Gbp) and the scan kernel leaves most of HBM's bandwidth unused (its
+// limit is the rate of scattered requests), so batch i+1's stream is packed into a SECOND buffer on a
+// side stream as soon as the batch that last read that buffer (i-1) has finished, instead of in front of its own scan.
+// Costs 0.375 B per base of context; everything else of a batch stays in order on the context's stream.
+bool ensure_pack_ahead(dcn_ctx *c) {
+    if (c->pack_ahead_state != 0) return c->pack_ahead_state > 0;
+    c->pack_ahead_state = -1;
+    if (getenv("DCN_NO_PACK_AHEAD")) return false;
+    bool ok = hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 2; ++i)
+        ok = hipEventCreateWithFlags(&c->pack_done[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->buf_free[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void **)&c->d_packed_b, packed_words(c->max_bases) * sizeof(uint32_t)) == hipSuccess &&
+         hipMalloc((void **)&c->d_invmask_b, mask_words(c->max_bases) * sizeof(uint32_t)) == hipSuccess &&
+         hipMalloc((void **)&c->d_pack_status, 2 * sizeof(dcn_status)) == hipSuccess;
+    if (ok) { // (pads in front of and behind the stream are read by the scan kernel: zero, as in the first buffer)
+        ok = hipMemset(c->d_packed_b, 0, packed_words(c->max_bases) * sizeof(uint32_t)) == hipSuccess &&
+             hipMemset(c->d_invmask_b, 0, mask_words(c->max_bases) * sizeof(uint32_t)) == hipSuccess &&
+             hipDeviceSynchronize() == hipSuccess; // null-stream memsets must not overtake the first pack
+    }
+    if (!ok) {
+        (void)hipGetLastError(); // no memory for a second stream: batches are packed in line, as before
+        if (c->d_packed_b) hipFree(c->d_packed_b);
+        if (c->d_invmask_b) hipFree(c->d_invmask_b);
+        if (c->d_pack_status) hipFree(c->d_pack_status);
+        c->d_packed_b = c->d_invmask_b = nullptr;
+        c->d_pack_status = nullptr;
+        return false;
+    }
+    c->pack_ahead_state = 1;
+    return true;
+}
+
 // enqueue the whole device pipeline for one view on the context's compute stream
-int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
+int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params, bool pack_ahead = false) {
     hipStream_t st = c->stream;
     const dcn_index *idx = c->index;
     // the per-unit scratch words are zero between batches (finish_kernel leaves them so); a run that did not get as
@@ -614,7 +666,26 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     int prof_slot = -1;
     DCN_TRY(prof_begin(c, &prof_slot));
     uint32_t *packed = v.d_packed + DCN_FRONT_PAD, *invmask = v.d_invmask + DCN_FRONT_PAD;
-    if (v.d_ascii) DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, c->d_status, st));
+    int ahead_buf = -1;
+    const uint32_t *newline_flag = nullptr;
+    // (per-stage profiling wants the stages one after the other on one stream: in line then)
+    if (v.d_ascii && pack_ahead && c->profiling != 1 && ensure_pack_ahead(c)) {
+        ahead_buf = c->pack_buf;
+        c->pack_buf ^= 1;
+        if (ahead_buf == 1) {
+            packed = c->d_packed_b + DCN_FRONT_PAD;
+            invmask = c->d_invmask_b + DCN_FRONT_PAD;
+        }
+        dcn_status *ps = c->d_pack_status + ahead_buf;
+        DCN_HIP(hipStreamWaitEvent(c->pack_stream, c->buf_free[ahead_buf], 0)); // (never recorded yet: no wait)
+        DCN_HIP(hipMemsetAsync(ps, 0, sizeof(dcn_status), c->pack_stream));
+        DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
+        DCN_HIP(hipEventRecord(c->pack_done[ahead_buf], c->pack_stream));
+        DCN_HIP(hipStreamWaitEvent(st, c->pack_done[ahead_buf], 0));
+        newline_flag = &ps->any_newline;
+    } else if (v.d_ascii) {
+        DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, c->d_status, st));
+    }
     DCN_PROF_MARK(DCN_STAGE_PACK);
 
     const uint32_t n_reads = v.n_reads, n_units = v.n_units;
@@ -640,6 +711,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     pa.tile_cursor = &c->d_status->n_tiles;
     pa.tiles = c->d_tiles;
     pa.status = c->d_status;
+    pa.newline_flag = newline_flag;
     DCN_TRY(dcn_launch_plan(pa, st));
     DCN_PROF_MARK(DCN_STAGE_PLAN);
 
@@ -737,6 +809,9 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params) {
     fa.status = c->d_status;
     DCN_TRY(dcn_launch_finish(fa, st));
     c->scratch_dirty = false;
+    // the next pack into the buffer this batch read may start (a batch packed in line between packed-ahead ones -- per-stage
+    // profiling -- read the first buffer)
+    if (pack_ahead && c->pack_ahead_state == 1) DCN_HIP(hipEventRecord(c->buf_free[ahead_buf >= 0 ? ahead_buf : 0], st));
     DCN_PROF_MARK(DCN_STAGE_FINISH);
     if (prof_slot >= 0) c->prof_used[prof_slot] = true;
     return DCN_OK;
@@ -1391,7 +1466,7 @@ extern "C" int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, con
     v.d_hits = d_hits;
     v.d_total = d_total;
     v.d_report = ctx->d_report;
-    DCN_TRY(enqueue_batch(ctx, v, params));
+    DCN_TRY(enqueue_batch(ctx, v, params, /*pack_ahead=*/true));
     ctx->batch_pending = true;
     return DCN_OK;
 }

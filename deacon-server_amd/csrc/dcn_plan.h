@@ -24,6 +24,8 @@ struct dcn_plan_args {
     uint32_t *tile_read_pos; // null, or per tile the position of its scan_start in its read (minimizer dump)
     uint32_t *tile_cursor;      // global tile counter (= &status->n_tiles, zeroed per batch)
     dcn_status *status;
+    const uint32_t *newline_flag; // null: status->any_newline; else the word the pack kernel of this batch wrote (it may have
+                                  // run ahead of the batch's own status words: api.hip, pack one batch ahead)
 };
 
 struct dcn_distinct_args {

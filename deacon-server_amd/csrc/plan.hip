@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     if (tid == 0) n_long = 0;
     // the one-byte probe for a trailing '\n' costs a 64-byte sector per read: skipped when the batch came packed
     // (a.ascii == null) or when the pack kernel, which reads every byte anyway, saw no '\n' at all
-    const uint8_t *ascii = (a.ascii && a.status->any_newline) ? a.ascii : nullptr;
+    const uint8_t *ascii = (a.ascii && (a.newline_flag ? *a.newline_flag : a.status->any_newline)) ? a.ascii : nullptr;
     uint32_t nwin[PLAN_CH], nt[PLAN_CH], loc[PLAN_CH];
     const bool two_classes = a.unit_id == nullptr;
     uint32_t carry = 0;  // tiles of the chunks before this one: all of them, or (two classes) those of multi-tile reads

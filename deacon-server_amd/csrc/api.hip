@@ -627,7 +627,11 @@ bool ensure_pack_ahead(dcn_ctx *c) {
     if (c->pack_ahead_state != 0) return c->pack_ahead_state > 0;
     c->pack_ahead_state = -1;
     if (getenv("DCN_NO_PACK_AHEAD")) return false;
-    bool ok = hipStreamCreateWithFlags(&c->pack_stream, hipStreamNonBlocking) == hipSuccess;
+    // (highest priority: the scan kernel's grid is 150 k workgroups deep, and a queue of ordinary priority only gets its
+    // turn when that grid has drained)
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    bool ok = hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, getenv("DCN_PACK_AHEAD_PRIO0") ? prio_low : prio_high) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
         ok = hipEventCreateWithFlags(&c->pack_done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->buf_free[i], hipEventDisableTiming) == hipSuccess;
@@ -679,7 +683,8 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params, bool
         dcn_status *ps = c->d_pack_status + ahead_buf;
         DCN_HIP(hipStreamWaitEvent(c->pack_stream, c->buf_free[ahead_buf], 0)); // (never recorded yet: no wait)
         DCN_HIP(hipMemsetAsync(ps, 0, sizeof(dcn_status), c->pack_stream));
-        DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
+        if (getenv("DCN_PACK_AHEAD_WG256")) DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
+        else DCN_TRY(dcn_launch_pack_beside(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
         DCN_HIP(hipEventRecord(c->pack_done[ahead_buf], c->pack_stream));
         DCN_HIP(hipStreamWaitEvent(st, c->pack_done[ahead_buf], 0));
         newline_flag = &ps->any_newline;

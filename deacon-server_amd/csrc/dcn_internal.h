@@ -186,7 +186,11 @@ struct dcn_scan_args {
 // packs bases [base_begin, base_end) of the stream (whole 32-base groups; bytes at or past base_end read as 'A');
 // status (may be null) receives any_newline
 int dcn_launch_pack(const uint8_t *d_ascii, uint64_t base_begin, uint64_t base_end, uint32_t *d_packed,
-                    uint32_t *d_invmask, dcn_status *status, hipStream_t stream, bool index_side = false);
+                    uint32_t *d_invmask, dcn_status *status, hipStream_t stream, bool index_side = false,
+                    uint32_t block_threads = 256);
+// ... as a kernel of <= 32 VGPRs in one-wave workgroups, to run beside another kernel's waves (pack.hip)
+int dcn_launch_pack_beside(const uint8_t *d_ascii, uint64_t base_begin, uint64_t base_end, uint32_t *d_packed, uint32_t *d_invmask,
+                           dcn_status *status, hipStream_t stream);
 int dcn_launch_scan(const dcn_scan_args &args, uint32_t max_tiles, bool dump, hipStream_t stream);
 
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n);

@@ -9,6 +9,8 @@
 // needs to know where reads begin.  HBM-bound: 1 B/bp read, 0.375 B/bp written.
 #include "dcn_internal.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ inline uint32_t pack4(uint32_t x) {
@@ -103,18 +105,66 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
 }
 
 
+// The same for a batch that is packed BESIDE another kernel's waves (api.hip packs batch i+1 while the scan kernel of batch i
+// runs): the scan kernel holds 4 waves x 120 VGPRs of a SIMD's 512, so only a wave of <= 32 VGPRs fits next to them.  Each
+// thread packs 16 bases (one uint4 in, one packed word and half a mask word out), one-wave workgroups, whole 16-base pieces
+// of a 16-byte-aligned stream only (dcn_launch_pack_beside leaves the rest to the general kernel).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void pack16_kernel(
+    const uint8_t *__restrict__ ascii, uint32_t *__restrict__ packed, uint32_t *__restrict__ invmask, uint32_t h_first,
+    uint32_t h_end, dcn_status *status) {
+    const uint32_t stride = gridDim.x * 64u;
+    uint32_t nl = 0;
+    uint16_t *mask16 = reinterpret_cast<uint16_t *>(invmask);
+    for (uint32_t t = h_first + blockIdx.x * 64u + threadIdx.x; t < h_end; t += stride) { // whole 16-base pieces only
+        const uint4 a = *reinterpret_cast<const uint4 *>(ascii + (uint64_t)t * 16);
+        const uint32_t p = pack4(a.x) | (pack4(a.y) << 8) | (pack4(a.z) << 16) | (pack4(a.w) << 24);
+        const uint32_t m = invalid4(a.x) | (invalid4(a.y) << 4) | (invalid4(a.z) << 8) | (invalid4(a.w) << 12);
+        if (m) {
+            uint32_t z = a.x ^ 0x0A0A0A0Au;
+            nl |= (z - 0x01010101u) & ~z & 0x80808080u;
+            z = a.y ^ 0x0A0A0A0Au;
+            nl |= (z - 0x01010101u) & ~z & 0x80808080u;
+            z = a.z ^ 0x0A0A0A0Au;
+            nl |= (z - 0x01010101u) & ~z & 0x80808080u;
+            z = a.w ^ 0x0A0A0A0Au;
+            nl |= (z - 0x01010101u) & ~z & 0x80808080u;
+        }
+        packed[t] = p;
+        mask16[t] = (uint16_t)m;
+    }
+    if (nl && status) status->any_newline = 1;
+}
+
 } // namespace
 
+int dcn_launch_pack_beside(const uint8_t *d_ascii, uint64_t base_begin, uint64_t base_end, uint32_t *d_packed, uint32_t *d_invmask,
+                           dcn_status *status, hipStream_t stream) {
+    if (base_end <= base_begin) return DCN_OK;
+    // whole 32-base groups by the small kernel, the (at most one) group that the stream's end cuts by the general one
+    const uint64_t whole_end = base_end / 32 * 32;
+    if ((reinterpret_cast<uintptr_t>(d_ascii) & 15) != 0 || (base_begin & 31) != 0 || whole_end / 16 > 0xFFFFFFFFull || whole_end <= base_begin)
+        return dcn_launch_pack(d_ascii, base_begin, base_end, d_packed, d_invmask, status, stream, false, 64);
+    const uint32_t h_first = (uint32_t)(base_begin / 16), h_end = (uint32_t)(whole_end / 16);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(((uint64_t)(h_end - h_first) + 63) / 64, 256ull * 4 * 16);
+    hipLaunchKernelGGL(pack16_kernel, dim3(blocks), dim3(64), 0, stream, d_ascii, d_packed, d_invmask, h_first, h_end, status);
+    DCN_HIP(hipGetLastError());
+    if (whole_end < base_end) return dcn_launch_pack(d_ascii, whole_end, base_end, d_packed, d_invmask, status, stream, false, 64);
+    return DCN_OK;
+}
+
 int dcn_launch_pack(const uint8_t *d_ascii, uint64_t base_begin, uint64_t base_end, uint32_t *d_packed,
-                    uint32_t *d_invmask, dcn_status *status, hipStream_t stream, bool index_side) {
+                    uint32_t *d_invmask, dcn_status *status, hipStream_t stream, bool index_side, uint32_t block_threads) {
     if (base_end <= base_begin) return DCN_OK;
     const uint64_t g_first = base_begin / 32, n_bases = base_end;
     uint64_t n_chunks = (base_end + 31) / 32 - g_first;
-    uint32_t blocks = (uint32_t)((n_chunks + 255) / 256);
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    // block_threads = 64: one-wave workgroups, which fit into any single wave slot another kernel's waves leave behind
+    // (api.hip packs the next batch beside the running scan kernel); 256 otherwise
+    const uint32_t bt = block_threads == 64 ? 64u : 256u;
+    uint32_t blocks = (uint32_t)((n_chunks + bt - 1) / bt);
+    if (blocks > 256 * 32 * (256 / bt)) blocks = 256 * 32 * (256 / bt);
     bool aligned = (reinterpret_cast<uintptr_t>(d_ascii) & 15) == 0;
 #define DCN_PACK(AL, IX) \
-    hipLaunchKernelGGL((pack_kernel<AL, IX>), dim3(blocks), dim3(256), 0, stream, d_ascii, n_bases, d_packed, d_invmask, g_first, n_chunks, status)
+    hipLaunchKernelGGL((pack_kernel<AL, IX>), dim3(blocks), dim3(bt), 0, stream, d_ascii, n_bases, d_packed, d_invmask, g_first, n_chunks, status)
     if (index_side) {
         if (aligned) DCN_PACK(true, true);
         else DCN_PACK(false, true);

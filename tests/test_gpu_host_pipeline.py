@@ -411,3 +411,57 @@ def test_contexts_on_several_threads_pack_side_by_side(oracle, dcn, genome, inde
             assert_same(got[t][i], want[t][i])
     for p in procs:
         p.close()
+
+
+def test_device_pointer_batches_queued_back_to_back(oracle, dcn, genome, index_pair, monkeypatch):
+    """Round 4: on the device-pointer API the pack kernel of batch i+1 runs on a side stream, into a second packed buffer,
+    while the kernels of batch i run (csrc/api.hip, ensure_pack_ahead).  Nine batches of three different shapes -- sizes that
+    differ by 4 x, reads with N and trailing newlines (the pack kernel's newline flag travels with its buffer), pairs -- are
+    queued without a synchronize in between, each with result arrays of its own; every one must give the oracle's
+    results.  Then the same with the side stream switched off, and with per-stage profiling on (which packs in line)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    oidx, gidx = index_pair
+    rng = np.random.default_rng(91)
+    shapes = []
+    for n_short, n_long, paired, newline in ((2500, 6, False, False), (600, 1, True, False), (1200, 3, False, True)):
+        reads = mixed_reads(rng, genome, n_short=n_short, n_long=n_long)
+        if newline:
+            reads = [r + b"\n" if i % 3 == 0 and len(r) else r for i, r in enumerate(reads)]
+        if paired and len(reads) % 2:
+            reads.pop()
+        b, o = oracle.concat_reads(reads)
+        uid = (np.arange(len(reads)) // 2).astype(np.uint32) if paired else None
+        shapes.append((b, o, uid, len(reads) // 2 if paired else len(reads)))
+    cap_b, cap_r = max(len(s[0]) for s in shapes) + 64, max(len(s[1]) for s in shapes)
+    for mode in ("ahead", "inline", "profiled"):
+        if mode == "inline":
+            monkeypatch.setenv("DCN_NO_PACK_AHEAD", "1")
+        else:
+            monkeypatch.delenv("DCN_NO_PACK_AHEAD", raising=False)
+        proc = dcn.FilterProcessor(gidx, deplete=True, max_batch_bases=cap_b, max_batch_reads=cap_r)
+        want = [oracle_batch(oracle, oidx, proc, b, o, uid) for b, o, uid, _ in shapes]
+        if mode == "profiled":
+            proc.set_profiling(1)
+        dev_in = [(torch.from_numpy(b).to(dev), torch.from_numpy(o.view(np.int64)).to(dev),
+                   None if uid is None else torch.from_numpy(uid.view(np.int32)).to(dev)) for b, o, uid, _ in shapes]
+        torch.cuda.synchronize()
+        outs = []
+        for i in range(9):
+            b, o, uid, nu = shapes[i % 3]
+            d_b, d_o, d_u = dev_in[i % 3]
+            k = torch.zeros(nu, dtype=torch.uint8, device=dev)
+            h = torch.zeros(nu, dtype=torch.int32, device=dev)
+            t = torch.zeros(nu, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()  # (the result arrays are zeroed on torch's stream)
+            proc.filter_batch_device(d_b.data_ptr(), d_o.data_ptr(), len(o) - 1, len(b), k.data_ptr(), h.data_ptr(), t.data_ptr(),
+                                     d_unit_id=None if d_u is None else d_u.data_ptr(), n_units=nu)
+            outs.append((k, h, t))
+        proc.synchronize()
+        for i, (k, h, t) in enumerate(outs):
+            w = want[i % 3]
+            assert t.cpu().numpy().tolist() == w[2].tolist(), (mode, i)
+            assert h.cpu().numpy().tolist() == w[1].tolist(), (mode, i)
+            assert k.cpu().numpy().astype(bool).tolist() == w[0].tolist(), (mode, i)
+        assert proc.stats()["total_seqs"] == 3 * sum(len(s[1]) - 1 for s in shapes)
+        proc.close()

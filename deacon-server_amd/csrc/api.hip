@@ -396,7 +396,7 @@ struct dcn_ctx {
     hipStream_t pack_stream = nullptr;
     uint32_t *d_packed_b = nullptr, *d_invmask_b = nullptr;
     dcn_status *d_pack_status = nullptr; // [2]
-    hipEvent_t pack_done[2] = {}, buf_free[2] = {};
+    hipEvent_t pack_done[2] = {}, buf_free[2] = {}, plan_done = nullptr;
     int pack_buf = 0, pack_ahead_state = 0; // 0 = not tried yet, 1 = ready, -1 = off (DCN_NO_PACK_AHEAD, or no memory for it)
     static constexpr int N_STAGE = 3, N_EV = 8, N_SLOTS = 2;
     hipEvent_t copy_done = nullptr, stage_free[N_STAGE] = {};
@@ -523,6 +523,7 @@ void free_ctx(dcn_ctx *c) {
         if (c->pack_done[i]) hipEventDestroy(c->pack_done[i]);
         if (c->buf_free[i]) hipEventDestroy(c->buf_free[i]);
     }
+    if (c->plan_done) hipEventDestroy(c->plan_done);
     if (c->d_packed_b) hipFree(c->d_packed_b);
     if (c->d_invmask_b) hipFree(c->d_invmask_b);
     if (c->d_pack_status) hipFree(c->d_pack_status);
@@ -618,20 +619,25 @@ struct BatchView {
     dcn_batch_report *d_report = nullptr;
 };
 
-// Device-pointer API: the pack kernel of batch i+1 runs beside the scan kernel of batch i.  The pack is a streaming kernel
-// (1 B/bp in, 0.375 out: 0.39 ms of a 3.7 ms step at 1.5 Gbp) and the scan kernel leaves most of HBM's bandwidth unused (its
-// limit is the rate of scattered requests), so batch i+1's stream is packed into a SECOND buffer on a
-// side stream as soon as the batch that last read that buffer (i-1) has finished, instead of in front of its own scan.
+// Device-pointer API, experiment kept behind DCN_PACK_AHEAD=1: the pack kernel of batch i+1 runs beside the scan kernel of
+// batch i.  The pack is a streaming kernel (1 B/bp in, 0.375 out: 0.39 ms of a 3.7 ms step at 1.5 Gbp) and the scan kernel
+// moves only 38 % of HBM's peak, so batch i+1's stream is packed into a SECOND buffer on a side stream once the batch that
+// last read that buffer (i-1) has finished and batch i's plan kernel is through, instead of in front of its own scan.
 // Costs 0.375 B per base of context; everything else of a batch stays in order on the context's stream.
 bool ensure_pack_ahead(dcn_ctx *c) {
     if (c->pack_ahead_state != 0) return c->pack_ahead_state > 0;
     c->pack_ahead_state = -1;
-    if (getenv("DCN_NO_PACK_AHEAD")) return false;
+    // OFF unless asked for (DCN_PACK_AHEAD=1): measured in round 4 (profiles/r04_ab.txt section 4), it buys nothing.  The two
+    // kernels do run side by side (kernel trace), and the scan kernel then takes longer by exactly the pack's time (3.30 ->
+    // 3.67 ms, step 3.85 -> 3.88): what the scan kernel leaves of HBM's bandwidth is not spare -- its scattered sectors and
+    // the pack's stream wait for the same DRAM cycles.
+    if (!getenv("DCN_PACK_AHEAD") || getenv("DCN_NO_PACK_AHEAD")) return false;
     // (highest priority: the scan kernel's grid is 150 k workgroups deep, and a queue of ordinary priority only gets its
     // turn when that grid has drained)
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
     bool ok = hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, getenv("DCN_PACK_AHEAD_PRIO0") ? prio_low : prio_high) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->plan_done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
         ok = hipEventCreateWithFlags(&c->pack_done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->buf_free[i], hipEventDisableTiming) == hipSuccess;
@@ -682,6 +688,10 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params, bool
         }
         dcn_status *ps = c->d_pack_status + ahead_buf;
         DCN_HIP(hipStreamWaitEvent(c->pack_stream, c->buf_free[ahead_buf], 0)); // (never recorded yet: no wait)
+        // ... and not before the previous batch's plan kernel is through: its buffer is free from the moment the batch
+        // before that one finished, which is just when the previous batch's (small, latency-bound) plan kernel starts --
+        // packing beside THAT only delays the scan kernel behind it (kernel trace: plan 0.10 -> 0.47 ms)
+        if (!getenv("DCN_PACK_AHEAD_EARLY")) DCN_HIP(hipStreamWaitEvent(c->pack_stream, c->plan_done, 0));
         DCN_HIP(hipMemsetAsync(ps, 0, sizeof(dcn_status), c->pack_stream));
         if (getenv("DCN_PACK_AHEAD_WG256")) DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
         else DCN_TRY(dcn_launch_pack_beside(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
@@ -718,6 +728,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params, bool
     pa.status = c->d_status;
     pa.newline_flag = newline_flag;
     DCN_TRY(dcn_launch_plan(pa, st));
+    if (pack_ahead && c->pack_ahead_state == 1) DCN_HIP(hipEventRecord(c->plan_done, st));
     DCN_PROF_MARK(DCN_STAGE_PLAN);
 
     uint32_t *g_total = c->d_unit_scratch, *g_hitcnt = g_total + c->max_reads, *g_distinct = g_hitcnt + c->max_reads,

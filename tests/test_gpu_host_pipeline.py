@@ -414,11 +414,11 @@ def test_contexts_on_several_threads_pack_side_by_side(oracle, dcn, genome, inde
 
 
 def test_device_pointer_batches_queued_back_to_back(oracle, dcn, genome, index_pair, monkeypatch):
-    """Round 4: on the device-pointer API the pack kernel of batch i+1 runs on a side stream, into a second packed buffer,
-    while the kernels of batch i run (csrc/api.hip, ensure_pack_ahead).  Nine batches of three different shapes -- sizes that
+    """Round 4: on the device-pointer API the pack kernel of batch i+1 can run on a side stream, into a second packed buffer,
+    while the kernels of batch i run (csrc/api.hip, ensure_pack_ahead; DCN_PACK_AHEAD=1 -- off by default, it bought nothing).  Nine batches of three different shapes -- sizes that
     differ by 4 x, reads with N and trailing newlines (the pack kernel's newline flag travels with its buffer), pairs -- are
     queued without a synchronize in between, each with result arrays of its own; every one must give the oracle's
-    results.  Then the same with the side stream switched off, and with per-stage profiling on (which packs in line)."""
+    results.  Then the same in the default order (packed in line), and with per-stage profiling on (which packs in line too)."""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
     oidx, gidx = index_pair
@@ -436,9 +436,9 @@ def test_device_pointer_batches_queued_back_to_back(oracle, dcn, genome, index_p
     cap_b, cap_r = max(len(s[0]) for s in shapes) + 64, max(len(s[1]) for s in shapes)
     for mode in ("ahead", "inline", "profiled"):
         if mode == "inline":
-            monkeypatch.setenv("DCN_NO_PACK_AHEAD", "1")
+            monkeypatch.delenv("DCN_PACK_AHEAD", raising=False)
         else:
-            monkeypatch.delenv("DCN_NO_PACK_AHEAD", raising=False)
+            monkeypatch.setenv("DCN_PACK_AHEAD", "1")
         proc = dcn.FilterProcessor(gidx, deplete=True, max_batch_bases=cap_b, max_batch_reads=cap_r)
         want = [oracle_batch(oracle, oidx, proc, b, o, uid) for b, o, uid, _ in shapes]
         if mode == "profiled":

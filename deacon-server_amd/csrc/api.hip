@@ -118,6 +118,16 @@ extern "C" int dcn_index_from_file(const char *path, int device, dcn_index **out
     if (!out) return dcn_fail(DCN_ERR_ARG, "out is NULL");
     *out = nullptr;
     if (!path) return dcn_fail(DCN_ERR_ARG, "path is NULL");
+    // The reference's file format has no room for the rule its keys were selected by (src/index.rs:17-31: version, k, w):
+    // a file is taken to have been built under the rule in force now.  Under the default that is what every existing
+    // file was built by; under any other setting (the parity-pinning switch) say so once, since a mismatch would probe
+    // with the wrong minimizers and raise no error.
+    if (dcn_current_variant() != DCN_VARIANT_DEFAULT && !getenv("DCN_QUIET")) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            std::fprintf(stderr, "deacon-hip: loading an index file under a non-default minimizer rule (dcn_set_minimizer_variant): "
+                                 "the file carries no marker of the rule it was built by and is assumed to match\n");
+    }
     // files whose hashes are all 9-byte varints (every hash >= 2^32: all of them, in practice) are decoded on
     // the device while they stream in; anything else takes the host decoder below
     bool handled = false;

@@ -646,7 +646,7 @@ bool ensure_pack_ahead(dcn_ctx *c) {
     // turn when that grid has drained)
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    bool ok = hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, getenv("DCN_PACK_AHEAD_PRIO0") ? prio_low : prio_high) == hipSuccess;
+    bool ok = hipStreamCreateWithPriority(&c->pack_stream, hipStreamNonBlocking, prio_high) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->plan_done, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i)
         ok = hipEventCreateWithFlags(&c->pack_done[i], hipEventDisableTiming) == hipSuccess &&
@@ -703,8 +703,7 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params, bool
         // packing beside THAT only delays the scan kernel behind it (kernel trace: plan 0.10 -> 0.47 ms)
         if (!getenv("DCN_PACK_AHEAD_EARLY")) DCN_HIP(hipStreamWaitEvent(c->pack_stream, c->plan_done, 0));
         DCN_HIP(hipMemsetAsync(ps, 0, sizeof(dcn_status), c->pack_stream));
-        if (getenv("DCN_PACK_AHEAD_WG256")) DCN_TRY(dcn_launch_pack(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
-        else DCN_TRY(dcn_launch_pack_beside(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
+        DCN_TRY(dcn_launch_pack_beside(v.d_ascii, v.b0, v.b1, packed, invmask, ps, c->pack_stream));
         DCN_HIP(hipEventRecord(c->pack_done[ahead_buf], c->pack_stream));
         DCN_HIP(hipStreamWaitEvent(st, c->pack_done[ahead_buf], 0));
         newline_flag = &ps->any_newline;

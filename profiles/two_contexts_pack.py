@@ -60,7 +60,7 @@ def main():
     sys.path.insert(0, ROOT)
     import bench
     cores = bench.host_cores()
-    reads, calls = 4_000_000, 8
+    reads, calls = int(os.environ.get("DCN_TCP_READS", "4000000")), int(os.environ.get("DCN_TCP_CALLS", "8"))
     out = {"cpus": cores, "reads_per_call": reads, "calls_per_context": calls, "legs": []}
     for threads in sorted({max(2, min(12, cores // 2)), max(2, min(24, cores))}):
         for n_ctx in (1, 2):

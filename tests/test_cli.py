@@ -457,7 +457,8 @@ def _long_and_short_records(rng, genome, n_short=400):
         s = int(rng.integers(0, len(genome) - ln))
         recs.append(mutate(rng, genome[s:s + ln], 0.02) if rng.random() < 0.5 else random_reads(rng, 1, ln, ln, p_n=0.01)[0])
     order = rng.permutation(len(recs))
-    return [recs[i] for i in order]
+    # (in front, in this order: a long-long pair, a long-short pair and a short-long pair for the paired mode)
+    return [recs[0], recs[1], recs[2], recs[-1], recs[-2], recs[4]] + [recs[i] for i in order if i not in (0, 1, 2, 4, len(recs) - 1, len(recs) - 2)]
 
 
 @gpu

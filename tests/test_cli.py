@@ -462,7 +462,7 @@ def _long_and_short_records(rng, genome, n_short=400):
 
 
 @gpu
-@pytest.mark.parametrize("mode", ["search", "deplete", "prefix", "paired"])
+@pytest.mark.parametrize("mode", ["search", "deplete", "prefix", "paired", "gzip-stdin"])
 def test_records_longer_than_the_largest_call(tmp_path, oracle, monkeypatch, mode):
     """the reference takes records of any length (src/local_filter.rs:346-374).  With the largest call
     shrunk to 20 kbp and pieces of 3 kbp, a dozen records go piece by piece -- dozens of seams each, on N runs, ties and
@@ -477,9 +477,11 @@ def test_records_longer_than_the_largest_call(tmp_path, oracle, monkeypatch, mod
     monkeypatch.setenv("DCN_CLI_MAX_BATCH_BASES", "20000")
     monkeypatch.setenv("DCN_CLI_GIANT_PIECE", "3000")
     b, o = oracle.concat_reads(recs)
-    flags = {"search": ["-a", 2, "-r", 0.01], "deplete": ["-d", "-a", 1, "-r", 0.02], "prefix": ["-p", 7000, "-r", 0.05], "paired": ["-d"]}[mode]
+    flags = {"search": ["-a", 2, "-r", 0.01], "deplete": ["-d", "-a", 1, "-r", 0.02], "prefix": ["-p", 7000, "-r", 0.05], "paired": ["-d"],
+             "gzip-stdin": ["-a", 2, "-r", 0.01]}[mode]
     kw = {"search": dict(abs_threshold=2, rel_threshold=0.01), "deplete": dict(abs_threshold=1, rel_threshold=0.02, deplete=True),
-          "prefix": dict(rel_threshold=0.05, prefix_length=7000), "paired": dict(deplete=True)}[mode]
+          "prefix": dict(rel_threshold=0.05, prefix_length=7000), "paired": dict(deplete=True),
+          "gzip-stdin": dict(abs_threshold=2, rel_threshold=0.01)}[mode]
     if mode == "paired":
         fasta(tmp_path / "r1.fa", [(f"r{i}/1", recs[2 * i].decode()) for i in range(len(recs) // 2)])
         fasta(tmp_path / "r2.fa", [(f"r{i}/2", recs[2 * i + 1].decode()) for i in range(len(recs) // 2)])
@@ -490,7 +492,11 @@ def test_records_longer_than_the_largest_call(tmp_path, oracle, monkeypatch, mod
         # 70-column FASTA: the long records are multi-line
         (tmp_path / "r.fa").write_bytes(b"".join(b">r%d\n" % i + b"\n".join(r[j:j + 70] for j in range(0, len(r), 70)) + b"\n"
                                                  for i, r in enumerate(recs)))
-        out = run("filter", *flags, idx, tmp_path / "r.fa").stdout.decode()
+        if mode == "gzip-stdin":  # the chunk reader's path: a compressed stream on stdin, chunks of 1 MB (records cross them)
+            monkeypatch.setenv("DCN_CLI_CHUNK_MB", "1")
+            out = run("filter", *flags, idx, "-", stdin=gzip.compress((tmp_path / "r.fa").read_bytes(), 1), env=dict(os.environ)).stdout.decode()
+        else:
+            out = run("filter", *flags, idx, tmp_path / "r.fa").stdout.decode()
         keep, _, _ = oracle.filter_batch(oidx, b, o, **kw)
         want = [f"r{i}" for i in range(len(recs)) if keep[i]]
     got = [l[1:] for l in out.split("\n") if l.startswith(">")]

@@ -186,3 +186,19 @@ def test_integration_md_binds_every_export(dcn):
         rret, rargs = r[name]
         assert rret == (None if ret == "void" else _rust_of_c(ret)), (name, ret, rret)
         assert rargs == [_rust_of_c(a) for a in args], (name, args, rargs)
+
+
+def test_abi_version_of_header_library_and_bindings_agree(dcn):
+    """DCN_ABI_MAJOR / DCN_ABI_MINOR of the header == what the built library reports == what the Python mirror was written
+    against (it refuses to load a library of another major); INTEGRATION.md's Rust constants say the same."""
+    import ctypes
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "deacon_hip.h")).read()
+    major = int(re.search(r"#define DCN_ABI_MAJOR (\d+)", header).group(1))
+    minor = int(re.search(r"#define DCN_ABI_MINOR (\d+)", header).group(1))
+    a, b = ctypes.c_uint32(), ctypes.c_uint32()
+    assert dcn._native.lib().dcn_abi_version(ctypes.byref(a), ctypes.byref(b)) == 0
+    assert (a.value, b.value) == (major, minor) == tuple(dcn._native.ABI)
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert f"pub const DCN_ABI_MAJOR: u32 = {major};" in md and f"pub const DCN_ABI_MINOR: u32 = {minor};" in md

@@ -904,14 +904,14 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
 
 // A few host threads that split one large job (a copy or a pack) into slices: a single core moves ~10 GB/s into
 // the pinned staging buffer, which is less than the PCIe link takes out of it.  Process-wide, created on first
-// use; DCN_HOST_THREADS sets the width (default: the usable CPUs, at most 12; 1 = run inline).
+// use; DCN_HOST_THREADS sets the width (default: the usable CPUs, at most 16; 1 = run inline).
 //
 // Several jobs at a time (round 4).  A job is `width()` slices; the caller's thread and the pool's workers CLAIM slices
 // one by one, from whichever of the jobs in flight has any left, so the contexts of one process -- deacon::MultiGpuFilter,
 // `deacon-hip filter --gpus N`, a Rust host with one worker thread per GPU -- pack their pageable input side by side
 // instead of taking turns behind one GPU's packing (the one-job-at-a-time rule of rounds 2-3: DESIGN.md section 5).  The
 // workers are shared and the scheme is work-conserving: one context alone still gets all of them.  With contexts on more
-// than one device the pool grows (ensure_devices: up to 12 threads per device in use, never beyond the CPUs the process
+// than one device the pool grows (ensure_devices: up to 16 threads per device in use, never beyond the CPUs the process
 // may use), which is what a per-device pool would give without idling one device's threads while another's pack runs.
 class HostPool {
   public:
@@ -978,10 +978,10 @@ class HostPool {
             if (hi > lo) memcpy((uint8_t *)dst + lo, (const uint8_t *)src + lo, hi - lo);
         }, n < par_min);
     }
-    // contexts exist on `n_devices` devices of this process: up to 12 threads per device, within the CPUs we may use
+    // contexts exist on `n_devices` devices of this process: up to 16 threads per device, within the CPUs we may use
     void ensure_devices(int n_devices) {
         if (fixed_ || slices_ <= 1) return;
-        const int want = std::min(cpus_, 12 * std::max(1, n_devices));
+        const int want = std::min(cpus_, 16 * std::max(1, n_devices));
         std::lock_guard<std::mutex> g(mu_);
         while ((int)workers_.size() + 1 < want) {
             const int i = (int)workers_.size() + 1;
@@ -1031,7 +1031,7 @@ class HostPool {
     }
     HostPool() {
         // CPUs this process may really use: the affinity mask, capped by the cgroup quota (a container often sees all of
-        // the host's hardware threads but is throttled to a share of them); at most 12 of those per device in use
+        // the host's hardware threads but is throttled to a share of them); at most 16 of those per device in use
         unsigned hw = std::thread::hardware_concurrency();
         cpu_set_t set;
         if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::min<unsigned>(hw ? hw : 1024, (unsigned)CPU_COUNT(&set));
@@ -1042,7 +1042,9 @@ class HostPool {
             fclose(f);
         }
         cpus_ = (int)std::max(1u, hw);
-        int want = std::min(12, cpus_);
+        // (at most 16: same-box sweeps of the host legs, round 4: 16 threads 100-105 / 103-111 Gbp/s on pageable input against 88-99 /
+        // 99-102 with 12, on a share of 16 CPUs -- the pool's threads claim slices, so an oversubscribed one is late, not idle)
+        int want = std::min(16, cpus_);
         if (const char *e = getenv("DCN_HOST_THREADS")) {
             want = atoi(e);
             fixed_ = true;

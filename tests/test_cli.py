@@ -588,7 +588,11 @@ def test_multi_gpu_driver_gives_the_single_context_output(tmp_path, oracle, pair
     b, o = oracle.concat_reads(reads)
     monkeypatch.setenv("DCN_CLI_MAX_BATCH_READS", "500")  # many calls, so that every context gets work
     outs = {}
-    for name, extra in (("one", []), ("three", ["--devices", "0,0,0"]), ("gpus1", ["--gpus", "1"])):
+    # "three-ascii": the batches stay ASCII (DCN_CLI_NO_PACKED_PARSE), so the library's host pool packs them -- three contexts'
+    # packing jobs side by side on its shared workers (round 4)
+    for name, extra in (("one", []), ("three", ["--devices", "0,0,0"]), ("gpus1", ["--gpus", "1"]), ("three-ascii", ["--devices", "0,0,0"])):
+        if name == "three-ascii":
+            monkeypatch.setenv("DCN_CLI_NO_PACKED_PARSE", "1")
         summ = tmp_path / f"{name}.json"
         if paired:
             for m in (1, 2):
@@ -602,7 +606,7 @@ def test_multi_gpu_driver_gives_the_single_context_output(tmp_path, oracle, pair
             p = run("filter", "-d", idx, tmp_path / "r.fq.gz", "-s", summ, *extra)
         sj = json.loads(summ.read_text())
         outs[name] = (p.stdout, {k_: sj[k_] for k_ in ("seqs_in", "seqs_out", "bp_in", "bp_out", "seqs_removed", "bp_removed")})
-    assert outs["three"] == outs["one"] == outs["gpus1"]
+    assert outs["three"] == outs["one"] == outs["gpus1"] == outs["three-ascii"]
     uid = (np.arange(4000) // 2).astype(np.uint32) if paired else None
     keep, _, _ = oracle.filter_batch(oidx, b, o, uid, deplete=True)
     ids = [l[1:] for l in outs["three"][0].decode().split("\n")[0::4] if l]

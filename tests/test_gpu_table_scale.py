@@ -228,3 +228,151 @@ def test_one_host_batch_beyond_2_to_the_32_bases(oracle, dcn):
     kp = proc.filter_batch_packed(packed, mask, offsets, counts=False)
     assert (np.asarray(kp).reshape(reps, nb) == np.asarray(want[0])[None, :]).all()
     proc.close()
+
+
+@pytest.mark.gpu
+def test_size_independent_properties_at_the_headline_batch(oracle, dcn):
+    """BASELINE.json configs[1] at its full size -- 10 M x 150 bp = 1.5 Gbp in one batch against a panhuman-1-sized table
+    (409,913,780 keys, 34 GB) -- through properties that need no oracle of that size:
+      * strand symmetry: the reverse complement of a read of A/C/G/T has the same minimizer multiset, hence the same total,
+        distinct hits and decision (a read with an N is exempt: N packs to G's code (c >> 1) & 3 on both strands --
+        SURVEY.md 8a row A2 -- so its two strands are not each other's complement in the 2-bit stream, and the reference's
+        choice of minimizers around it is strand-dependent too);
+      * idempotence: the same batch twice gives the same arrays;
+      * order invariance: the batch with its reads permuted gives the permuted arrays (every wave then holds other reads);
+      * decisions only == counting, and the six counters follow from the arrays;
+      * a checksum of the per-read results of the first 30 k reads against the CPU oracle on the index keys those reads can
+        touch (membership of the synthetic remainder follows from its definition, as in the 950 M-key test above)."""
+    torch = pytest.importorskip("torch")
+    import bench
+    dev = torch.device("cuda:0")
+    genome = bench.make_host_genome(64_000_000, 3, dev)
+    index, keys, host_keys, n_rand, _ = bench.build_index(genome, bench.PANHUMAN_KEYS, 0)
+    del keys
+    n = 10_000_000
+    fwd = bench.make_reads(genome, n, 5, dev)                              # (n * 150,) ASCII, half host-derived, 0.1 % N
+    rc = bench._revcomp_ascii(fwd.reshape(n, 150)).reshape(-1).contiguous()
+    off = torch.arange(n + 1, dtype=torch.int64, device=dev) * 150
+    proc = dcn.FilterProcessor(index, max_batch_bases=n * 150, max_batch_reads=n)
+
+    def run(bases, counts=True):
+        k = torch.zeros(n, dtype=torch.uint8, device=dev)
+        h = torch.zeros(n, dtype=torch.int32, device=dev) if counts else None
+        t = torch.zeros(n, dtype=torch.int32, device=dev) if counts else None
+        torch.cuda.synchronize()
+        proc.filter_batch_device(bases.data_ptr(), off.data_ptr(), n, n * 150, k.data_ptr(), h.data_ptr() if counts else None,
+                                 t.data_ptr() if counts else None)
+        proc.synchronize()
+        return k, h, t
+
+    proc.reset_stats()
+    k1, h1, t1 = run(fwd)
+    st = proc.stats()
+    assert st["total_seqs"] == n and st["total_bp"] == n * 150
+    assert st["filtered_seqs"] == n - int(k1.sum(dtype=torch.int64).item())            # search mode: kept = matched
+    assert st["output_bp"] == 150 * int(k1.sum(dtype=torch.int64).item())
+    k2, h2, t2 = run(fwd)
+    assert torch.equal(k1, k2) and torch.equal(h1, h2) and torch.equal(t1, t2)        # idempotence
+    k3, h3, t3 = run(rc)
+    clean = ~(fwd.reshape(n, 150) == ord("N")).any(dim=1)
+    assert 0.8 < float(clean.float().mean().item()) < 0.99
+    assert torch.equal(t1[clean], t3[clean]) and torch.equal(h1[clean], h3[clean]) and torch.equal(k1[clean], k3[clean])  # strand symmetry
+    kd, _, _ = run(fwd, counts=False)
+    assert torch.equal(kd, k1)                                                         # decisions only == counting
+    perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    shuffled = fwd.reshape(n, 150)[perm].reshape(-1).contiguous()
+    k4, h4, t4 = run(shuffled)
+    assert torch.equal(k4, k1[perm]) and torch.equal(h4, h1[perm]) and torch.equal(t4, t1[perm])   # order invariance
+    # plausibility of the whole batch, then exactness on a sample
+    assert 0.45 < float(k1.float().mean().item()) < 0.55 and int(t1.min().item()) >= 0 and 12.5 < float(t1.float().mean().item()) < 15.5
+    m = 30_000
+    b = fwd[:m * 150].cpu().numpy()
+    o = np.arange(m + 1, dtype=np.uint64) * np.uint64(150)
+    small = bench.touchable_oracle_index(b, o, host_keys, n_rand, 8)
+    keep, hits, total = oracle.filter_batch(small, b, o, None, 2, 0.01, 0, False, threads=8)
+    assert total.tolist() == t1[:m].cpu().numpy().tolist()
+    assert hits.tolist() == h1[:m].cpu().numpy().tolist()
+    assert keep.tolist() == k1[:m].cpu().numpy().astype(bool).tolist()
+    proc.close()
+    index.close()
+
+
+@pytest.mark.gpu
+def test_size_independent_properties_of_long_reads_and_pairs_at_full_size(oracle, dcn):
+    """BASELINE.json configs[2] (ONT-style lognormal reads, mean 10 kbp, 1.5 Gbp per batch: every read spans waves, the run
+    export and the distinct pass carry the counts) and configs[3] (5 M pairs of 2 x 150 bp, --deplete) at their full sizes
+    against the panhuman-1-sized table, through properties:
+      long reads -- idempotence; strand symmetry (these reads hold no N); the reads in reverse ORDER give the reversed
+        arrays (other tiles share every wave); decisions only == counting; first reads == the CPU oracle;
+      pairs -- a pair's total is the sum of its mates' totals as single reads, its distinct hits lie between the larger
+        mate's and the sum; swapping the mates of every pair changes nothing (src/filter_common.rs:312-348: the hashes are
+        concatenated, hits are distinct across both); decisions only == counting."""
+    torch = pytest.importorskip("torch")
+    import bench
+    dev = torch.device("cuda:0")
+    genome = bench.make_host_genome(64_000_000, 3, dev)
+    index, keys, host_keys, n_rand, _ = bench.build_index(genome, bench.PANHUMAN_KEYS, 0)
+    del keys
+
+    def run(proc, bases, off, n_reads, n_units, uid=None, counts=True):
+        k = torch.zeros(n_units, dtype=torch.uint8, device=dev)
+        h = torch.zeros(n_units, dtype=torch.int32, device=dev) if counts else None
+        t = torch.zeros(n_units, dtype=torch.int32, device=dev) if counts else None
+        torch.cuda.synchronize()
+        proc.filter_batch_device(bases.data_ptr(), off.data_ptr(), n_reads, int(bases.numel()), k.data_ptr(),
+                                 h.data_ptr() if counts else None, t.data_ptr() if counts else None,
+                                 d_unit_id=None if uid is None else uid.data_ptr(), n_units=n_units)
+        proc.synchronize()
+        return k, h, t
+
+    # ---- configs[2] ------------------------------------------------------------------------------------------------
+    lb, lo = bench.make_long_reads(genome, 1_500_000_000, 6, dev)
+    n = lo.numel() - 1
+    proc = dcn.FilterProcessor(index, max_batch_bases=int(lb.numel()), max_batch_reads=n)
+    proc.reserve_records(int(lb.numel()) // 6)
+    k1, h1, t1 = run(proc, lb, lo, n, n)
+    k2, h2, t2 = run(proc, lb, lo, n, n)
+    assert torch.equal(k1, k2) and torch.equal(h1, h2) and torch.equal(t1, t2)
+    kd, _, _ = run(proc, lb, lo, n, n, counts=False)
+    assert torch.equal(kd, k1)
+    # reverse complement of every read = the whole stream reverse-complemented, reads in reverse order
+    comp = torch.arange(256, dtype=torch.uint8, device=dev)
+    for a_, b_ in zip(b"ACGT", b"TGCA"):
+        comp[a_] = b_
+    rcb = comp[lb.flip(0).long()].contiguous()
+    lens = (lo[1:] - lo[:-1]).flip(0)
+    rco = torch.zeros_like(lo)
+    rco[1:] = torch.cumsum(lens, 0)
+    k3, h3, t3 = run(proc, rcb, rco, n, n)
+    assert torch.equal(t3.flip(0), t1) and torch.equal(h3.flip(0), h1) and torch.equal(k3.flip(0), k1)
+    assert 0.4 < float(k1.float().mean().item()) < 0.6 and float(t1.float().sum().item()) > 0.115 * lb.numel()
+    m = int(torch.searchsorted(lo, torch.tensor([30_000_000], device=dev)).item()) - 1
+    b = lb[:int(lo[m].item())].cpu().numpy()
+    o = lo[:m + 1].cpu().numpy().astype(np.uint64)
+    small = bench.touchable_oracle_index(b, o, host_keys, n_rand, 8)
+    keep, hits, total = oracle.filter_batch(small, b, o, None, 2, 0.01, 0, False, threads=8)
+    assert total.tolist() == t1[:m].cpu().numpy().tolist() and hits.tolist() == h1[:m].cpu().numpy().tolist()
+    assert keep.tolist() == k1[:m].cpu().numpy().astype(bool).tolist()
+    proc.close()
+    del lb, rcb, lo, rco
+    torch.cuda.empty_cache()
+
+    # ---- configs[3] ------------------------------------------------------------------------------------------------
+    n_pairs = 5_000_000
+    pb = bench.make_pairs(genome, n_pairs, 7, dev)                                      # rows 2i, 2i+1 = the mates of pair i
+    nr = 2 * n_pairs
+    off = torch.arange(nr + 1, dtype=torch.int64, device=dev) * 150
+    uid = (torch.arange(nr, dtype=torch.int32, device=dev) // 2).contiguous()
+    proc = dcn.FilterProcessor(index, deplete=True, max_batch_bases=nr * 150, max_batch_reads=nr)
+    kp, hp, tp = run(proc, pb, off, nr, n_pairs, uid)
+    ks, hs, ts = run(proc, pb, off, nr, nr)                                              # the same reads as single units
+    assert torch.equal(tp, ts[0::2] + ts[1::2])
+    assert bool((hp <= hs[0::2] + hs[1::2]).all()) and bool((hp >= torch.maximum(hs[0::2], hs[1::2])).all())
+    swapped = pb.reshape(n_pairs, 2, 150).flip(1).reshape(-1).contiguous()
+    kq, hq, tq = run(proc, swapped, off, nr, n_pairs, uid)
+    assert torch.equal(kq, kp) and torch.equal(hq, hp) and torch.equal(tq, tp)
+    kd, _, _ = run(proc, pb, off, nr, n_pairs, uid, counts=False)
+    assert torch.equal(kd, kp)
+    assert 0.45 < float(kp.float().mean().item()) < 0.55                                 # --deplete keeps the random half
+    proc.close()
+    index.close()

@@ -77,7 +77,12 @@ bool ends_with(const std::string &s, const char *suf) {
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
+size_t usable_cpus();  // (below) the CPUs this process may really use
+
 // ---- input: plain, gzip, zstd or xz by content, file or stdin (niffler's role in src/local_filter.rs:41-55) ---------
+// A gzip input made of BGZF members (bgzip / htslib, and what several sequencer pipelines write: every member <= 64 KB and
+// carrying its own length) is inflated on several threads, 16 MB of members at a time -- 1.0 GB/s on 4 threads, 1.5 on 8,
+// against 0.35 GB/s for zlib on one stream, which is what bounds every other gzip input (and the reference's reader).
 class Input {
   public:
     explicit Input(const std::string &path) : raw_(1 << 20) {
@@ -91,6 +96,9 @@ class Input {
             kind_ = GZIP;
             std::memset(&zs_, 0, sizeof zs_);
             if (inflateInit2(&zs_, 15 + 32) != Z_OK) die("zlib initialisation failed");
+            // blocked gzip (BGZF: what bgzip, htslib and several sequencer pipelines write): every member says how long it
+            // is, so members are found without inflating them and inflated side by side (see fill_bgzf)
+            bgzf_ = bgzf_block_size(m, n) != 0 && !std::getenv("DCN_CLI_NO_BGZF");
         } else if (codecs::is_zstd_magic(m, n)) {
             kind_ = ZSTD;
             zstd_ = codecs::Zstd::get(&why);
@@ -122,6 +130,12 @@ class Input {
                 std::memcpy(dst + got, raw_.data() + pos_, m);
                 pos_ += m;
                 got += m;
+            } else if (kind_ == GZIP && bgzf_) {
+                if (bz_pos_ == bz_out_.size() && !fill_bgzf()) continue;  // (nothing more in blocked form: the stream path takes over, or the input has ended)
+                const size_t take = std::min(n - got, bz_out_.size() - bz_pos_);
+                std::memcpy(dst + got, bz_out_.data() + bz_pos_, take);
+                bz_pos_ += take;
+                got += take;
             } else if (kind_ == GZIP) {
                 if (!avail && raw_eof_) {
                     if (mid_stream_) die("read error: truncated gzip stream");
@@ -166,6 +180,118 @@ class Input {
     }
 
   private:
+    // BGZF: a gzip member whose extra field holds the subfield 'B','C' with the member's total size - 1 (SAM spec 4.1).
+    // Returns that total size, or 0 when the bytes at p are not the start of such a member (or too few to tell).
+    static size_t bgzf_block_size(const unsigned char *p, size_t n) {
+        if (n < 18 || p[0] != 0x1F || p[1] != 0x8B || p[2] != 8 || !(p[3] & 4)) return 0;
+        const size_t xlen = p[10] | (size_t)p[11] << 8;
+        if (n < 12 + xlen) return 0;
+        for (size_t o = 12; o + 4 <= 12 + xlen;) {
+            const size_t slen = p[o + 2] | (size_t)p[o + 3] << 8;
+            if (p[o] == 'B' && p[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) return (size_t)(p[o + 4] | (size_t)p[o + 5] << 8) + 1;
+            o += 4 + slen;
+        }
+        return 0;
+    }
+    // Reads the next run of BGZF members (up to ~16 MB of them) and inflates them on a few threads, each member into its
+    // own place of bz_out_ (its uncompressed size is its last four bytes).  false: no blocked member at the read position --
+    // the input has ended, or an ordinary member follows (`cat a.bgz b.gz`): from there on the stream decoder reads.
+    bool fill_bgzf() {
+        bz_out_.clear();
+        bz_pos_ = 0;
+        struct Blk {
+            size_t in_off, in_len, out_off, out_len;
+        };
+        std::vector<Blk> blks;
+        size_t out_total = 0;
+        bz_in_.clear();
+        for (;;) {
+            // at least a header's worth of bytes in raw_ (a member is at most 64 KB, raw_ is 1 MB)
+            if (end_ - pos_ < 18 && !raw_eof_) {
+                std::memmove(raw_.data(), raw_.data() + pos_, end_ - pos_);
+                end_ -= pos_;
+                pos_ = 0;
+                top_up();
+            }
+            const size_t bs = bgzf_block_size((const unsigned char *)raw_.data() + pos_, end_ - pos_);
+            if (bs == 0) break;
+            if (end_ - pos_ < bs) {
+                if (raw_eof_) die("read error: truncated gzip stream");
+                std::memmove(raw_.data(), raw_.data() + pos_, end_ - pos_);
+                end_ -= pos_;
+                pos_ = 0;
+                top_up();
+                if (end_ - pos_ < bs) {
+                    if (raw_eof_) die("read error: truncated gzip stream");
+                    continue;
+                }
+            }
+            const unsigned char *b = (const unsigned char *)raw_.data() + pos_;
+            const size_t xlen = b[10] | (size_t)b[11] << 8;
+            if (bs < 12 + xlen + 8) die("read error: invalid gzip stream");
+            const size_t isize = b[bs - 4] | (size_t)b[bs - 3] << 8 | (size_t)b[bs - 2] << 16 | (size_t)b[bs - 1] << 24;
+            if (isize > 65536) die("read error: invalid gzip stream");
+            blks.push_back({bz_in_.size(), bs, out_total, isize});
+            bz_in_.insert(bz_in_.end(), b, b + bs);
+            out_total += isize;
+            pos_ += bs;
+            if (out_total >= (16u << 20)) break;
+        }
+        if (blks.empty()) {
+            if (end_ == pos_ && raw_eof_) done_ = true;  // end of input (the empty end-of-file member has been passed)
+            else bgzf_ = false;                           // an ordinary member: the stream decoder goes on from pos_
+            return false;
+        }
+        bz_out_.resize(out_total);
+        size_t nthreads = std::min<size_t>(std::max<size_t>(1, usable_cpus() / 2), 8);
+        if (const char *e = std::getenv("DCN_CLI_BGZF_THREADS")) nthreads = (size_t)std::max(1, std::atoi(e));
+        nthreads = std::min(nthreads, blks.size());
+        std::atomic<size_t> next{0};
+        std::atomic<bool> bad{false};
+        auto work = [&] {
+            z_stream z;
+            std::memset(&z, 0, sizeof z);
+            if (inflateInit2(&z, -15) != Z_OK) {
+                bad = true;
+                return;
+            }
+            for (size_t i; (i = next.fetch_add(1)) < blks.size();) {
+                const Blk &k = blks[i];
+                const unsigned char *b = bz_in_.data() + k.in_off;
+                const size_t xlen = b[10] | (size_t)b[11] << 8;
+                z.next_in = (Bytef *)(b + 12 + xlen);
+                z.avail_in = (uInt)(k.in_len - 12 - xlen - 8);
+                unsigned char none = 0;  // (an empty member -- the end-of-file marker -- still wants a place to write to)
+                z.next_out = k.out_len ? (Bytef *)(bz_out_.data() + k.out_off) : &none;
+                z.avail_out = (uInt)k.out_len;
+                const int r = k.out_len ? inflate(&z, Z_FINISH) : inflate(&z, Z_SYNC_FLUSH);
+                const uLong crc = crc32(crc32(0L, Z_NULL, 0), k.out_len ? (const Bytef *)(bz_out_.data() + k.out_off) : &none, (uInt)k.out_len);
+                const uLong want = b[k.in_len - 8] | (uLong)b[k.in_len - 7] << 8 | (uLong)b[k.in_len - 6] << 16 | (uLong)b[k.in_len - 5] << 24;
+                if (r != Z_STREAM_END || z.avail_out != 0 || crc != want) bad = true;
+                if (inflateReset(&z) != Z_OK) bad = true;
+            }
+            inflateEnd(&z);
+        };
+        std::vector<std::thread> ts;
+        for (size_t t = 1; t < nthreads; ++t) ts.emplace_back(work);
+        work();
+        for (auto &t : ts) t.join();
+        if (bad) die("read error: invalid gzip stream");
+        return true;
+    }
+    // more bytes behind end_ (refill() starts over at 0; here what is left stays in front)
+    void top_up() {
+        while (end_ < raw_.size() && !raw_eof_) {
+            ssize_t r = ::read(fd_, raw_.data() + end_, raw_.size() - end_);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                die("read error");
+            }
+            if (r == 0) raw_eof_ = true;
+            else end_ += (size_t)r;
+            if (end_ >= 65536 + 4096) break;
+        }
+    }
     void refill() {
         pos_ = end_ = 0;
         while (end_ < raw_.size() && !raw_eof_) {
@@ -184,6 +310,10 @@ class Input {
     std::vector<char> raw_;
     size_t pos_ = 0, end_ = 0;
     bool raw_eof_ = false, done_ = false, mid_stream_ = false;
+    bool bgzf_ = false;                    // the members at the read position are BGZF blocks
+    std::vector<unsigned char> bz_in_;     // a run of whole members ...
+    std::vector<char> bz_out_;             // ... and what they inflate to
+    size_t bz_pos_ = 0;
     z_stream zs_;
     const codecs::Zstd *zstd_ = nullptr;
     void *zds_ = nullptr;
@@ -2425,6 +2555,26 @@ int main(int argc, char **argv) {
             if (pos.size() > 2) a.input2 = pos[2], a.has_input2 = true;
             if (pos.size() > 3) die("unexpected argument '" + pos[3] + "'");
             return run_filter(a);
+        }
+        if (args[0] == "cat" && args.size() >= 2) {  // hidden: the input side alone (format found by content, decoded to stdout; no GPU)
+            Input in(args[1]);
+            std::vector<char> buf(8u << 20);
+            const auto t0 = std::chrono::steady_clock::now();
+            uint64_t total = 0;
+            for (size_t got; (got = in.read(buf.data(), buf.size())) > 0;) {
+                total += got;
+                if (args.size() < 3 || args[2] != "--count") {
+                    size_t w = 0;
+                    while (w < got) {
+                        const ssize_t r = ::write(1, buf.data() + w, got - w);
+                        if (r < 0) die("write error");
+                        w += (size_t)r;
+                    }
+                }
+            }
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "decoded %llu bytes in %.3f s: %.2f GB/s\n", (unsigned long long)total, sec, total / sec / 1e9);
+            return 0;
         }
         if (args[0] == "bench-parse" && args.size() >= 2) {  // hidden: the parser pool alone on a plain FASTX file (no GPU)
             size_t threads = 8;

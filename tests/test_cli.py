@@ -68,6 +68,51 @@ def test_filter_fails_loudly_without_gpu(tmp_path, dcn):
     assert p.returncode == 1 and b"Error" in p.stderr
 
 
+def bgzf_compress(data, block=65280, level=6, eof=True):
+    """BGZF (SAM spec 4.1), written by hand: gzip members of <= 64 KB whose extra field 'BC' holds the member's size - 1"""
+    import struct
+    import zlib
+    out = bytearray()
+
+    def member(chunk):
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        raw = c.compress(chunk) + c.flush()
+        out.extend(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25) + raw +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    for i in range(0, len(data), block):
+        member(data[i:i + block])
+    if eof:
+        member(b"")
+    return bytes(out)
+
+
+def test_blocked_gzip_input_is_inflated_member_by_member(tmp_path):
+    """`deacon-hip cat` = the tool's input side alone (no GPU).  BGZF members are found by their length field and inflated on
+    several threads; the bytes must be those of the stream decoder (DCN_CLI_NO_BGZF) for: a BGZF file with and without its
+    end-of-file member, BGZF followed by an ordinary member and the other way round (`cat a.bgz b.gz`), an ordinary gzip
+    file, tiny and empty inputs, stdin; a truncated or corrupted member is an error, not silence."""
+    rng = np.random.default_rng(3)
+    data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGTN"), int(rng.integers(20, 400))).astype(np.uint8)), b"I" * 7)
+                    for i in range(40_000))
+    cases = {"bgzf": (bgzf_compress(data), data), "bgzf-no-eof": (bgzf_compress(data, eof=False), data),
+             "bgzf-then-gzip": (bgzf_compress(data[:3_000_000], eof=False) + gzip.compress(data[3_000_000:], 1), data),
+             "gzip-then-bgzf": (gzip.compress(data[:1_000_000], 1) + bgzf_compress(data[1_000_000:]), data),
+             "gzip": (gzip.compress(data, 1), data), "small-blocks": (bgzf_compress(data[:500_000], block=777), data[:500_000]),
+             "tiny": (bgzf_compress(b"@a\nACGT\n+\nIIII\n"), b"@a\nACGT\n+\nIIII\n"), "empty": (bgzf_compress(b""), b"")}
+    for name, (blob, want) in cases.items():
+        f = tmp_path / f"{name}.gz"
+        f.write_bytes(blob)
+        for extra in ({}, {"DCN_CLI_NO_BGZF": "1"}, {"DCN_CLI_BGZF_THREADS": "1"}, {"DCN_CLI_BGZF_THREADS": "7"}):
+            p = run("cat", f, env=dict(os.environ, **extra))
+            assert p.stdout == want, (name, extra, len(p.stdout), len(want))
+        assert run("cat", "-", stdin=blob).stdout == want, name
+    whole = cases["bgzf"][0]
+    for bad in (whole[:len(whole) // 2], whole[:70_000] + bytes([whole[70_000] ^ 0x55]) + whole[70_001:]):
+        (tmp_path / "bad.gz").write_bytes(bad)
+        p = run("cat", tmp_path / "bad.gz", check=False)
+        assert p.returncode == 1 and b"gzip stream" in p.stderr
+
+
 # ---- the reference's filter tests ------------------------------------------------------------------------------------
 gpu = pytest.mark.gpu
 
@@ -568,6 +613,30 @@ def test_a_300_mbp_record_among_short_reads(tmp_path, oracle):
         s = json.loads(summ.read_text())
         assert s["seqs_in"] == len(recs) and s["bp_in"] == len(b)
     assert int(total[25]) > 30_000_000 and int(hits[25]) > int(total[25]) // 1000 and not keep[25]   # (the last run was -d: the match is dropped)
+
+
+@gpu
+def test_filter_reads_blocked_gzip_like_plain_files(tmp_path, oracle):
+    """the same reads as BGZF (single file through the chunk reader; two files of mates through the record reader) and as
+    plain files give the same output"""
+    rng = np.random.default_rng(64)
+    genome = random_reads(rng, 1, 60_000, 60_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    reads = []
+    for i in range(30_000):
+        ln = int(rng.integers(40, 300))
+        s_ = int(rng.integers(0, len(genome) - ln))
+        reads.append(mutate(rng, genome[s_:s_ + ln], 0.02) if i % 2 else random_reads(rng, 1, ln, ln)[0])
+    fq = "".join(f"@r{i}\n{r.decode()}\n+\n{'I' * len(r)}\n" for i, r in enumerate(reads)).encode()
+    (tmp_path / "r.fq").write_bytes(fq)
+    (tmp_path / "r.fq.gz").write_bytes(bgzf_compress(fq))
+    assert run("filter", idx, tmp_path / "r.fq.gz").stdout == run("filter", idx, tmp_path / "r.fq").stdout
+    m1 = "".join(f"@r{i}/1\n{reads[2 * i].decode()}\n+\n{'I' * len(reads[2 * i])}\n" for i in range(15_000)).encode()
+    m2 = "".join(f"@r{i}/2\n{reads[2 * i + 1].decode()}\n+\n{'I' * len(reads[2 * i + 1])}\n" for i in range(15_000)).encode()
+    for name, blob in (("m1.fq", m1), ("m2.fq", m2), ("m1.fq.gz", bgzf_compress(m1)), ("m2.fq.gz", bgzf_compress(m2, block=4000))):
+        (tmp_path / name).write_bytes(blob)
+    a = run("filter", "-d", idx, tmp_path / "m1.fq.gz", tmp_path / "m2.fq.gz").stdout
+    assert a == run("filter", "-d", idx, tmp_path / "m1.fq", tmp_path / "m2.fq").stdout and len(a) > 1000
 
 
 @gpu

@@ -53,7 +53,7 @@
 
 namespace {
 
-const char *VERSION = "0.3.0";
+const char *VERSION = "0.4.0";
 
 std::atomic<int> g_sparse_out_fds[2] = {{-1}, {-1}};  // output files still sized to their reservation (MappedOutput): cut on failure
 

@@ -362,9 +362,45 @@ class Output {
     static void compress_member(Codec codec, int level, const char *in, size_t n, std::vector<char> &out) {
         out.clear();
         if (codec == GZIP) {
+            // BGZF: members of <= 65,280 input bytes, each carrying its own compressed size in the 'BC' extra subfield (SAM
+            // spec 4.1).  Still a gzip file for every reader (zcat, python gzip, the reference's niffler), and one whose
+            // members a reader can find without inflating them: bgzip / htslib index it, and this tool's own input side
+            // inflates it on several threads (Input::fill_bgzf).  Costs 26 bytes and a fresh window per 64 KB (~2-3 % of size).
+            // DCN_CLI_GZIP_ONE_MEMBER=1 keeps the one member per batch of rounds 2-3.
+            static const bool one_member = std::getenv("DCN_CLI_GZIP_ONE_MEMBER") != nullptr;
             z_stream zs;
             std::memset(&zs, 0, sizeof zs);
-            if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("gzip initialisation failed");
+            if (deflateInit2(&zs, level, Z_DEFLATED, one_member ? 15 + 16 : -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("gzip initialisation failed");
+            if (!one_member) {
+                constexpr size_t BLOCK = 65280;
+                out.reserve(n / 3 + (n / BLOCK + 1) * 32 + 64);
+                size_t pos = 0;
+                do {  // (n == 0: one empty member, which is BGZF's end-of-file marker)
+                    const size_t take = std::min(BLOCK, n - pos);
+                    const size_t at = out.size();
+                    out.resize(at + 18 + deflateBound(&zs, (uLong)take) + 8);
+                    unsigned char *h = (unsigned char *)out.data() + at;
+                    static const unsigned char head[16] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0};
+                    std::memcpy(h, head, 16);
+                    zs.next_in = (Bytef *)(in + pos);
+                    zs.avail_in = (uInt)take;
+                    zs.next_out = h + 18;
+                    zs.avail_out = (uInt)(out.size() - at - 18 - 8);
+                    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("write error: gzip");
+                    const size_t clen = zs.total_out, total = 18 + clen + 8;
+                    if (total > 65536) die("write error: gzip member too large");
+                    h[16] = (unsigned char)((total - 1) & 0xFF);
+                    h[17] = (unsigned char)((total - 1) >> 8);
+                    const uLong crc = crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(in + pos), (uInt)take);
+                    unsigned char *t = h + 18 + clen;
+                    for (int i = 0; i < 4; ++i) t[i] = (unsigned char)(crc >> (8 * i)), t[4 + i] = (unsigned char)((uint32_t)take >> (8 * i));
+                    out.resize(at + total);
+                    pos += take;
+                    if (deflateReset(&zs) != Z_OK) die("write error: gzip");
+                } while (pos < n);
+                deflateEnd(&zs);
+                return;
+            }
             out.resize(deflateBound(&zs, (uLong)std::min<size_t>(n, 1u << 30)) + (n >> 10) + 64);  // grown below if short
             size_t in_pos = 0;
             for (;;) {
@@ -476,7 +512,9 @@ class Output {
     void close() {
         FILE *f = f_;
         if (!f) return;
-        if (codec_ != PLAIN && !wrote_member_) {  // nothing was kept: still a valid (empty) file of its format
+        // nothing was kept: still a valid (empty) file of its format; a gzip file of BGZF members ends with the empty member
+        // that bgzip / htslib read as "not truncated"
+        if (codec_ != PLAIN && (!wrote_member_ || (codec_ == GZIP && !std::getenv("DCN_CLI_GZIP_ONE_MEMBER")))) {
             compress_member(codec_, level_, "", 0, cbuf_);
             raw_write(cbuf_.data(), cbuf_.size());
         }

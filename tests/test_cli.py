@@ -193,6 +193,26 @@ def test_filter_compressed_outputs_and_inputs(tmp_path):  # filter_tests.rs:131-
         assert dec(out.read_bytes()) == plain_many, ext
         run("filter", "-d", idx, tmp_path / "reads.fastq", "-o", out)
         assert out.stat().st_size > 0 and dec(out.read_bytes()) == b"", ext
+    # a .gz output is a file of BGZF members (round 4): every member carries its size ('BC'), none holds more than 64 KB, the
+    # last one is bgzip's 28-byte end-of-file marker -- and the tool's own input side reads it member by member
+    big = [(f"b{i}", "".join("ACGT"[c] for c in rng.integers(0, 4, 150))) for i in range(3000)] + [("hit", SEQ1)]
+    fastq(tmp_path / "big.fastq", big)
+    run("filter", "-d", idx, tmp_path / "big.fastq", "-o", tmp_path / "big.fastq.gz")
+    blob = (tmp_path / "big.fastq.gz").read_bytes()
+    pos, members, sizes = 0, 0, []
+    while pos < len(blob):
+        assert blob[pos:pos + 4] == b"\x1f\x8b\x08\x04" and blob[pos + 12:pos + 16] == b"BC\x02\x00"
+        total = int.from_bytes(blob[pos + 16:pos + 18], "little") + 1
+        sizes.append(int.from_bytes(blob[pos + total - 4:pos + total], "little"))
+        pos += total
+        members += 1
+    assert pos == len(blob) and members >= 15 and max(sizes) <= 65536 and sizes[-1] == 0 and total == 28
+    want = run("filter", "-d", idx, tmp_path / "big.fastq").stdout
+    assert gzip.decompress(blob) == want and want.count(b"@b") == 3000
+    assert run("cat", tmp_path / "big.fastq.gz").stdout == want
+    assert run("cat", tmp_path / "big.fastq.gz", env=dict(os.environ, DCN_CLI_NO_BGZF="1")).stdout == want
+    run("filter", "-d", idx, tmp_path / "big.fastq", "-o", tmp_path / "one.fastq.gz", env=dict(os.environ, DCN_CLI_GZIP_ONE_MEMBER="1"))
+    assert gzip.decompress((tmp_path / "one.fastq.gz").read_bytes()) == want and (tmp_path / "one.fastq.gz").read_bytes()[3] != 4
     for ext, lo, hi in (("gz", 1, 9), ("zst", 1, 22), ("xz", 0, 9)):  # validate_compression_level, local_filter.rs:95-107
         p = run("filter", idx, tmp_path / "reads.fastq", "-o", tmp_path / f"x.{ext}", "--compression-level", hi + 1, check=False)
         assert p.returncode != 0 and b"compression level" in p.stderr, ext

@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "codecs.hpp"
+#include "fast_inflate.hpp"
 #include "deacon_hip.hpp"
 
 namespace {
@@ -99,6 +100,9 @@ class Input {
             // blocked gzip (BGZF: what bgzip, htslib and several sequencer pipelines write): every member says how long it
             // is, so members are found without inflating them and inflated side by side (see fill_bgzf)
             bgzf_ = bgzf_block_size(m, n) != 0 && !std::getenv("DCN_CLI_NO_BGZF");
+            // our own inflate (fast_inflate.hpp) unless zlib's is asked for: the same bytes out, the same errors
+            fast_ = !std::getenv("DCN_CLI_ZLIB_INFLATE");
+            if (fast_) gz_.reset(new fastgz::GzReader(&Input::gz_source, this));
         } else if (codecs::is_zstd_magic(m, n)) {
             kind_ = ZSTD;
             zstd_ = codecs::Zstd::get(&why);
@@ -136,6 +140,13 @@ class Input {
                 std::memcpy(dst + got, bz_out_.data() + bz_pos_, take);
                 bz_pos_ += take;
                 got += take;
+            } else if (kind_ == GZIP && fast_) {
+                const size_t r = gz_->read(dst + got, n - got);  // (takes its input through gz_source: raw_'s rest first, then the file)
+                if (r == 0) {
+                    if (!gz_->error().empty()) die("read error: " + gz_->error());
+                    done_ = true;
+                }
+                got += r;
             } else if (kind_ == GZIP) {
                 if (!avail && raw_eof_) {
                     if (mid_stream_) die("read error: truncated gzip stream");
@@ -180,6 +191,26 @@ class Input {
     }
 
   private:
+    // where fastgz::GzReader gets its bytes: what raw_ still holds, then the file itself (no second copy)
+    static size_t gz_source(void *ctx, unsigned char *dst, size_t cap) {
+        Input *self = (Input *)ctx;
+        if (self->pos_ < self->end_) {
+            const size_t m = std::min(cap, self->end_ - self->pos_);
+            std::memcpy(dst, self->raw_.data() + self->pos_, m);
+            self->pos_ += m;
+            return m;
+        }
+        while (!self->raw_eof_) {
+            const ssize_t r = ::read(self->fd_, dst, cap);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                die("read error");
+            }
+            if (r == 0) self->raw_eof_ = true;
+            return (size_t)r;
+        }
+        return 0;
+    }
     // BGZF: a gzip member whose extra field holds the subfield 'B','C' with the member's total size - 1 (SAM spec 4.1).
     // Returns that total size, or 0 when the bytes at p are not the start of such a member (or too few to tell).
     static size_t bgzf_block_size(const unsigned char *p, size_t n) {
@@ -248,7 +279,25 @@ class Input {
         nthreads = std::min(nthreads, blks.size());
         std::atomic<size_t> next{0};
         std::atomic<bool> bad{false};
-        auto work = [&] {
+        bz_in_.insert(bz_in_.end(), fastgz::PAD, 0);  // (the fast decoder loads eight bytes at a time, a little past the end)
+        auto work_fast = [&] {
+            // a member is decoded into a place with the slack the decoder writes into, checked, and copied to its own
+            std::unique_ptr<fastgz::BlockDecoder> dec(new fastgz::BlockDecoder());
+            std::vector<unsigned char> tmp(65536 + 258 + 16 + 64);
+            for (size_t i; (i = next.fetch_add(1)) < blks.size();) {
+                const Blk &k = blks[i];
+                const unsigned char *b = bz_in_.data() + k.in_off;
+                const size_t xlen = b[10] | (size_t)b[11] << 8;
+                const uint32_t want = b[k.in_len - 8] | (uint32_t)b[k.in_len - 7] << 8 | (uint32_t)b[k.in_len - 6] << 16 | (uint32_t)b[k.in_len - 5] << 24;
+                if (!fastgz::inflate_whole(*dec, b + 12 + xlen, k.in_len - 12 - xlen - 8, tmp.data(), k.out_len) ||
+                    fastgz::crc32_fast(0, tmp.data(), k.out_len) != want) {
+                    bad = true;
+                    continue;
+                }
+                if (k.out_len) std::memcpy(bz_out_.data() + k.out_off, tmp.data(), k.out_len);
+            }
+        };
+        auto work_zlib = [&] {
             z_stream z;
             std::memset(&z, 0, sizeof z);
             if (inflateInit2(&z, -15) != Z_OK) {
@@ -273,6 +322,7 @@ class Input {
             inflateEnd(&z);
         };
         std::vector<std::thread> ts;
+        auto work = [&] { fast_ ? work_fast() : work_zlib(); };
         for (size_t t = 1; t < nthreads; ++t) ts.emplace_back(work);
         work();
         for (auto &t : ts) t.join();
@@ -315,6 +365,8 @@ class Input {
     std::vector<char> bz_out_;             // ... and what they inflate to
     size_t bz_pos_ = 0;
     z_stream zs_;
+    bool fast_ = false;                    // gzip through fast_inflate.hpp (default) rather than zlib (DCN_CLI_ZLIB_INFLATE=1)
+    std::unique_ptr<fastgz::GzReader> gz_;
     const codecs::Zstd *zstd_ = nullptr;
     void *zds_ = nullptr;
     const codecs::Lzma *lzma_ = nullptr;

@@ -1,0 +1,176 @@
+"""The command-line tool's own gzip decoder (deacon-server_amd/cli/fast_inflate.hpp) against zlib, through `deacon-hip cat`
+(= the tool's input side alone, no GPU).  The reference reads compressed inputs through its readers' decoders
+(src/filter_common.rs:40-76 of the reference: paraseq / niffler over flate2); what has to hold here is that the bytes that
+come out are the bytes zlib makes of the same file, for every kind of deflate block and gzip header, and that a damaged
+file is an error and never different bytes."""
+import gzip
+import os
+import random
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "deacon-server_amd", "bin", "deacon-hip")
+ZLIB = dict(os.environ, DCN_CLI_ZLIB_INFLATE="1")
+
+
+def cat(blob, env=None, count=False):
+    p = subprocess.run([BIN, "cat", "-"] + (["--count"] if count else []), input=blob, capture_output=True, env=env)
+    return p.returncode, p.stdout, p.stderr.decode()
+
+
+def fastq_text(rng, n, quals=b"I"):
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+    for i in range(n):
+        m = int(rng.integers(30, 300))
+        q = bytes(rng.choice(np.frombuffer(quals, np.uint8), m)) if len(quals) > 1 else quals * m
+        out.append(b"@r%d\n%s\n+\n%s\n" % (i, alpha[rng.integers(0, 4, m)].tobytes(), q))
+    return b"".join(out)
+
+
+def member(data, flg=0, extra=b"", name=b"", comment=b"", level=6):
+    """one gzip member with the optional header fields FLG names (RFC 1952 2.3)"""
+    raw = zlib.compress(data, level)[2:-4]
+    h = bytearray(b"\x1f\x8b\x08" + bytes([flg]) + b"\0\0\0\0\0\xff")
+    if flg & 4:
+        h += struct.pack("<H", len(extra)) + extra
+    if flg & 8:
+        h += name + b"\0"
+    if flg & 16:
+        h += comment + b"\0"
+    if flg & 2:
+        h += struct.pack("<H", zlib.crc32(bytes(h)) & 0xFFFF)
+    return bytes(h) + raw + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data) & 0xFFFFFFFF)
+
+
+@pytest.fixture(scope="module")
+def payloads():
+    rng = np.random.default_rng(5)
+    return {
+        "empty": b"", "one": b"x",
+        "fastq": fastq_text(rng, 20_000),
+        "fastq-quals": fastq_text(rng, 8_000, quals=bytes(range(33, 74))),
+        "zeros": bytes(3_000_000),
+        "random": rng.integers(0, 256, 1_000_000, dtype=np.uint8).tobytes(),
+        "text": b"the quick brown fox jumps over the lazy dog. " * 30_000,
+        "runs": b"".join(bytes([i % 251]) * (i % 700 + 1) for i in range(4000)),
+        "period3": b"abc" * 300_000, "period7": b"abcdefg" * 200_000,
+        "skewed": bytes(rng.choice([65, 66, 67, 200, 201, 7], 1_000_000, p=[.9, .05, .02, .01, .01, .01]).astype(np.uint8)),
+        # 286 literal/length and 30 distance codes all in use, code lengths up to 15: long codes past the tables' bits
+        "geometric": bytes(np.minimum(rng.geometric(0.08, 1_500_000), 255).astype(np.uint8)),
+    }
+
+
+def test_every_kind_of_block_decodes_to_zlibs_bytes(payloads):
+    """stored (level 0), fixed-Huffman, dynamic at several levels, RLE / Huffman-only / filtered strategies, and streams cut
+    into many blocks by sync and full flushes (empty stored blocks between them)"""
+    for name, data in payloads.items():
+        blobs = {f"level{lv}": gzip.compress(data, lv) for lv in (0, 1, 6, 9)}
+        for sname, strat in (("fixed", zlib.Z_FIXED), ("rle", zlib.Z_RLE), ("huffman", zlib.Z_HUFFMAN_ONLY), ("filtered", zlib.Z_FILTERED)):
+            c = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strat)
+            blobs[sname] = c.compress(data) + c.flush()
+        c = zlib.compressobj(5, zlib.DEFLATED, 31)
+        parts = []
+        for i in range(0, len(data), 7777):
+            parts += [c.compress(data[i:i + 7777]), c.flush(zlib.Z_SYNC_FLUSH if i % 3 else zlib.Z_FULL_FLUSH)]
+        blobs["flushed"] = b"".join(parts) + c.flush()
+        for kind, blob in blobs.items():
+            rc, out, err = cat(blob)
+            assert rc == 0 and out == data, (name, kind, rc, len(out), len(data), err)
+
+
+def test_members_header_fields_and_padding(payloads):
+    fq = payloads["fastq"]
+    blob = (member(fq[:100_000], 8, name=b"a.fq") + member(b"") +
+            member(fq[100_000:300_000], 4 | 8 | 16 | 2, extra=b"XY\x03\x00abc", name=b"n", comment=b"c", level=1) + member(fq[300_000:], level=9))
+    assert cat(blob)[:2] == (0, fq)
+    assert cat(blob, env=ZLIB)[:2] == (0, fq)
+    # a header longer than one read of the input (an extra field of 60 KB and a long name)
+    big = member(fq[:50_000], 4 | 8, extra=b"ZZ" + struct.pack("<H", 60_000) + bytes(60_000), name=b"n" * 70_000)
+    assert cat(big + member(fq[50_000:]))[:2] == (0, fq)
+    # what follows the last member: zlib's reader refuses anything that is not a member; so does ours, with the same words
+    for tail in (bytes(100), b"garbage"):
+        a, b = cat(blob + tail), cat(blob + tail, env=ZLIB)
+        assert a[0] == b[0] == 1 and "invalid gzip stream" in a[2] and "invalid gzip stream" in b[2]
+
+
+def test_large_input_crosses_the_decoders_buffers(payloads):
+    """more than the decoder's 8 MB output buffer and 4 MB input buffer, blocks and matches across every refill; a slow pipe
+    that delivers the file in small pieces"""
+    data = payloads["fastq-quals"] * 12 + payloads["random"] * 3 + payloads["text"] * 4
+    for lv in (1, 6):
+        blob = gzip.compress(data, lv)
+        rc, out, err = cat(blob)
+        assert rc == 0 and out == data, (lv, err)
+    # stored blocks only, larger than the input buffer in total
+    assert cat(gzip.compress(data[:20_000_000], 0))[1] == data[:20_000_000]
+    blob = gzip.compress(data[:6_000_000], 6)
+    p = subprocess.Popen([BIN, "cat", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
+    import threading
+    got = []
+    t = threading.Thread(target=lambda: got.append(p.stdout.read()))
+    t.start()
+    for i in range(0, len(blob), 1013):
+        p.stdin.write(blob[i:i + 1013])
+        if i % (1013 * 64) == 0:
+            p.stdin.flush()
+    p.stdin.close()
+    t.join()
+    assert p.wait() == 0 and got[0] == data[:6_000_000]
+
+
+def test_damaged_files_are_errors_never_other_bytes(payloads):
+    fq = payloads["fastq"]
+    blob = gzip.compress(fq, 6)
+    for cut in (1, 5, 12, 1000, len(blob) // 2, len(blob) - 9, len(blob) - 3):
+        rc, out, err = cat(blob[:cut], count=True)
+        if cut < 2:
+            continue  # (a byte that is not a gzip magic is plain text to the tool)
+        assert rc == 1 and "gzip stream" in err, (cut, rc, err)
+    random.seed(3)
+    light = gzip.compress(fq[:300_000], 1)
+    accepted = 0
+    for t in range(120):
+        b = bytearray(blob[:200_000]) if t % 2 else bytearray(light)
+        for _ in range(random.randint(1, 4)):
+            i = random.randrange(10, len(b))
+            b[i] ^= 1 << random.randrange(8)
+        rc, out, err = cat(bytes(b))
+        assert rc in (0, 1), (t, rc, err)  # never a signal
+        if rc == 0:  # (rare: the flips cancelled out or hit a header field nobody checks) -- then zlib reads the same bytes
+            accepted += 1
+            assert out == gzip.decompress(bytes(b)), t
+    assert accepted < 10
+
+
+def test_blocked_gzip_members_take_the_same_decoder(payloads):
+    """BGZF members are inflated side by side (tests/test_cli.py has the member logic); here: the fast decoder on members of
+    every block kind, against zlib's on the same file"""
+    from test_cli import bgzf_compress
+    for name in ("fastq", "fastq-quals", "random", "zeros", "geometric", "empty"):
+        data = payloads[name][:2_000_000]
+        blob = bgzf_compress(data)
+        for env in (None, ZLIB, dict(os.environ, DCN_CLI_BGZF_THREADS="3")):
+            rc, out, err = cat(blob, env=env)
+            assert rc == 0 and out == data, (name, err)
+    # a member whose CRC or length field lies
+    blob = bytearray(bgzf_compress(payloads["fastq"][:200_000]))
+    first = (blob[16] | blob[17] << 8) + 1
+    blob[first - 8] ^= 1
+    rc, out, err = cat(bytes(blob))
+    assert rc == 1 and "gzip stream" in err
+
+
+def test_decoder_stays_inside_its_buffers_under_the_sanitizers(tmp_path):
+    """tests/cpp/fast_inflate_test.cpp with AddressSanitizer and UBSan (CPU build: the decoder is host code)"""
+    exe = tmp_path / "fast_inflate_test"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "deacon-server_amd", "cli"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "cpp", "fast_inflate_test.cpp"), "-lz"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith(b"bad 0"), (p.stdout[-500:], p.stderr[-3000:])

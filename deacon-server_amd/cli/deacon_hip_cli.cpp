@@ -50,6 +50,7 @@
 
 #include "codecs.hpp"
 #include "fast_inflate.hpp"
+#include "parallel_gzip.hpp"
 #include "deacon_hip.hpp"
 
 namespace {
@@ -102,7 +103,15 @@ class Input {
             bgzf_ = bgzf_block_size(m, n) != 0 && !std::getenv("DCN_CLI_NO_BGZF");
             // our own inflate (fast_inflate.hpp) unless zlib's is asked for: the same bytes out, the same errors
             fast_ = !std::getenv("DCN_CLI_ZLIB_INFLATE");
-            if (fast_) gz_.reset(new fastgz::GzReader(&Input::gz_source, this));
+            if (fast_) {
+                // one stream on several threads (parallel_gzip.hpp) where there are threads to be had
+                size_t workers = std::min<size_t>(std::max<size_t>(1, usable_cpus() / 2), 8);
+                if (const char *e = std::getenv("DCN_CLI_GZ_THREADS")) workers = (size_t)std::max(1, std::atoi(e));
+                size_t chunk = 2u << 20;  // (test hook: small chunks put every path of the reader to work on small files)
+                if (const char *e = std::getenv("DCN_CLI_GZ_CHUNK")) chunk = (size_t)std::max(4096, std::atoi(e));
+                if (workers > 1 && !std::getenv("DCN_CLI_NO_PARALLEL_GZ")) pgz_.reset(new fastgz::ParallelGzReader(&Input::gz_source, this, (unsigned)workers, chunk));
+                else gz_.reset(new fastgz::GzReader(&Input::gz_source, this));
+            }
         } else if (codecs::is_zstd_magic(m, n)) {
             kind_ = ZSTD;
             zstd_ = codecs::Zstd::get(&why);
@@ -126,8 +135,11 @@ class Input {
     size_t read(char *dst, size_t n) {
         size_t got = 0;
         while (got < n && !done_) {
-            if (pos_ == end_ && !raw_eof_) refill();
-            const size_t avail = end_ - pos_;
+            // (a gzip stream's reader fetches its own input through gz_source, the parallel one on a thread of its own: from
+            // its first call on, raw_ and the file belong to it)
+            const bool own_input = kind_ == GZIP && fast_ && !bgzf_;
+            if (!own_input && pos_ == end_ && !raw_eof_) refill();
+            const size_t avail = own_input ? 0 : end_ - pos_;
             if (kind_ == PLAIN) {
                 if (!avail) break;
                 const size_t m = std::min(avail, n - got);
@@ -141,9 +153,11 @@ class Input {
                 bz_pos_ += take;
                 got += take;
             } else if (kind_ == GZIP && fast_) {
-                const size_t r = gz_->read(dst + got, n - got);  // (takes its input through gz_source: raw_'s rest first, then the file)
+                // (either reader takes its input through gz_source: raw_'s rest first, then the file)
+                const size_t r = pgz_ ? pgz_->read(dst + got, n - got) : gz_->read(dst + got, n - got);
                 if (r == 0) {
-                    if (!gz_->error().empty()) die("read error: " + gz_->error());
+                    const std::string &err = pgz_ ? pgz_->error() : gz_->error();
+                    if (!err.empty()) die("read error: " + err);
                     done_ = true;
                 }
                 got += r;
@@ -367,6 +381,7 @@ class Input {
     z_stream zs_;
     bool fast_ = false;                    // gzip through fast_inflate.hpp (default) rather than zlib (DCN_CLI_ZLIB_INFLATE=1)
     std::unique_ptr<fastgz::GzReader> gz_;
+    std::unique_ptr<fastgz::ParallelGzReader> pgz_;
     const codecs::Zstd *zstd_ = nullptr;
     void *zds_ = nullptr;
     const codecs::Lzma *lzma_ = nullptr;

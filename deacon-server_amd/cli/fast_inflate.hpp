@@ -119,9 +119,14 @@ enum Status { OK = 0, NEED_INPUT = 1, NEED_ROOM = 2, BAD = 3 };
 // be missing) + 6 (one length/distance pair) + 7 (the loads in between) + 8 bytes past the end.
 constexpr size_t PAD = 64;
 
-class BlockDecoder {
+// T = the type of an output element: unsigned char for bytes; uint16_t where a decoder starts in the middle of a stream and
+// what lies before its start is not known yet (parallel_gzip.hpp: the 32 K elements in front of the output are then numbered
+// markers, and a match that reaches back to them copies markers instead of bytes).
+template <typename T>
+class BlockDecoderT {
   public:
     static constexpr int LIT_BITS = 11, DIST_BITS = 9;
+    static constexpr size_t SLACK = 258 + 16;  // elements behind out_end that may be written
     struct Bits {
         const unsigned char *in;
         uint64_t buf;
@@ -131,9 +136,9 @@ class BlockDecoder {
     // One deflate block starting at bit state `b` (updated on OK), written at `out` (advanced on OK).  `out_begin` is the oldest
     // byte a match may reach (>= 32 KB before `out` once that much has been produced), `out_end` the end of the buffer, `in_end`
     // the end of the input available; the input buffer must be readable for PAD bytes past in_end.  `final` returns BFINAL.
-    Status block(Bits &b, const unsigned char *in_end, unsigned char *out_begin, unsigned char *&out, unsigned char *out_end, bool &final) {
+    Status block(Bits &b, const unsigned char *in_end, T *out_begin, T *&out, T *out_end, bool &final) {
         Bits s = b;
-        unsigned char *o = out;
+        T *o = out;
         if (!need(s, in_end, 3)) return NEED_INPUT;
         final = (s.buf & 1) != 0;
         const unsigned type = (unsigned)(s.buf >> 1) & 3;
@@ -157,6 +162,13 @@ class BlockDecoder {
         b.buf = 0;
         b.cnt = 0;
     }
+    // the same at a bit position of the buffer `base` (a deflate block starts at any bit)
+    static void start_at_bit(Bits &b, const unsigned char *base, uint64_t bit) {
+        start(b, base + (bit >> 3));
+        refill(b);
+        drop(b, (unsigned)(bit & 7));
+    }
+    static uint64_t bit_position(const Bits &b, const unsigned char *base) { return (uint64_t)(b.in - base) * 8 - b.cnt; }
     // the byte position behind the bits consumed so far, rounded up to a whole byte (end of a deflate stream)
     static const unsigned char *byte_position(const Bits &b) { return b.in - (b.cnt >> 3); }
 
@@ -187,7 +199,7 @@ class BlockDecoder {
         return (int64_t)(s.in - in_end) * 8 > (int64_t)s.cnt;
     }
 
-    Status stored(Bits &s, const unsigned char *in_end, unsigned char *&o, unsigned char *out_end) {
+    Status stored(Bits &s, const unsigned char *in_end, T *&o, T *out_end) {
         drop(s, s.cnt & 7);
         const unsigned char *p = s.in - (s.cnt >> 3);
         if (in_end - p < 4) return NEED_INPUT;
@@ -196,16 +208,18 @@ class BlockDecoder {
         p += 4;
         if ((size_t)(in_end - p) < len) return NEED_INPUT;
         if ((size_t)(out_end - o) < len) return NEED_ROOM;
-        std::memcpy(o, p, len);
+        if (sizeof(T) == 1) std::memcpy(o, p, len);
+        else
+            for (unsigned i = 0; i < len; ++i) o[i] = (T)p[i];
         o += len;
         start(s, p + len);
         return OK;
     }
 
     // code lengths -> table of 2^bits entries + the canonical arrays for longer codes.  kind: 0 = literal / length alphabet,
-    // 1 = distance alphabet.  false: over-subscribed (an incomplete set is allowed, as zlib allows it for distances; its
-    // unused patterns decode as BAD)
-    static bool build(const uint8_t *lens, int n, int bits, int kind, uint32_t *table, Long &lg) {
+    // 1 = distance alphabet.  false: over-subscribed, or incomplete with a code longer than one bit -- zlib's rule
+    // (inftrees.c: "incomplete set" unless max == 1); the unused pattern of a one-code set decodes as BAD
+    static bool build(const uint8_t *lens, int n, int bits, int kind, uint32_t *table, Long &lg, bool strict = true) {
         static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
         static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
         static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -213,11 +227,13 @@ class BlockDecoder {
         std::memset(lg.count, 0, sizeof lg.count);
         for (int i = 0; i < n; ++i) lg.count[lens[i]]++;
         lg.count[0] = 0;
-        int left = 1;
+        int left = 1, max_len = 0;
         for (int l = 1; l <= 15; ++l) {
             left = (left << 1) - lg.count[l];
             if (left < 0) return false;
+            if (lg.count[l]) max_len = l;
         }
+        if (strict && left > 0 && max_len > 1) return false;
         uint16_t off = 0, code = 0;
         for (int l = 1; l <= 15; ++l) {
             code = (uint16_t)((code + lg.count[l - 1]) << 1);
@@ -310,7 +326,7 @@ class BlockDecoder {
         pair_literals(fixed_lit_, LIT_BITS, scratch_);
         uint8_t d[30];
         for (int i = 0; i < 30; ++i) d[i] = 5;
-        build(d, 30, DIST_BITS, 1, fixed_dist_, fixed_dist_long_);
+        build(d, 30, DIST_BITS, 1, fixed_dist_, fixed_dist_long_, false);  // (30 of the 32 five-bit codes: incomplete by definition)
         fixed_ready_ = true;
     }
 
@@ -377,6 +393,7 @@ class BlockDecoder {
         }
         for (int l = bits + 1; l <= 15; ++l)
             if (lg.count[l]) return false;
+        if (left != 0) return false;  // (zlib: an incomplete code-length code is always an error)
         uint16_t code = 0, nextc[16];
         for (int l = 1; l <= bits; ++l) {
             code = (uint16_t)((code + lg.count[l - 1]) << 1);
@@ -394,8 +411,8 @@ class BlockDecoder {
         return true;
     }
 
-    Status huffman(Bits &s, const unsigned char *in_end, unsigned char *out_begin, unsigned char *&o, unsigned char *out_end, const uint32_t *lit,
-                   const uint32_t *dist, const Long &lit_long, const Long &dist_long) {
+    Status huffman(Bits &s, const unsigned char *in_end, T *out_begin, T *&o, T *out_end, const uint32_t *lit, const uint32_t *dist,
+                   const Long &lit_long, const Long &dist_long) {
         static const uint16_t len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
         static const uint8_t len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
         static const uint16_t dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -403,7 +420,7 @@ class BlockDecoder {
         const uint32_t lit_mask = (1u << LIT_BITS) - 1, dist_mask = (1u << DIST_BITS) - 1;
         // the input is padded, so loads never fault; whether the bits consumed really existed is checked once per symbol group
         // against in_end (a block cut short decodes garbage from the padding, is refused, and is decoded again with more input)
-        unsigned char *const o_safe = out_end - (258 + 16);
+        T *const o_safe = out_end - SLACK;
         for (;;) {
             if (o > o_safe) return NEED_ROOM;
             refill(s);
@@ -414,8 +431,8 @@ class BlockDecoder {
                 // literals: up to four lookups per refill (4 x 11 bits < 56; a single literal of a lookup is <= 11 bits as well),
                 // each one or two bytes; the second byte of a single is written and overwritten (o moves by the count)
                 for (int q = 0;;) {
-                    o[0] = (unsigned char)(e >> 16);
-                    o[1] = (unsigned char)(e >> 8);
+                    o[0] = (T)(unsigned char)(e >> 16);
+                    o[1] = (T)(unsigned char)(e >> 8);
                     o += 1 + (e >> 26);  // kind 4 -> 2 bytes, kind 0 -> 1
                     drop(s, e & 0xFF);
                     if (++q == 4) break;
@@ -431,7 +448,7 @@ class BlockDecoder {
                 const int sym = long_symbol(s, lit_long, LIT_BITS);
                 if (sym < 0) return overran(s, in_end) ? NEED_INPUT : BAD;
                 if (sym < 256) {
-                    *o++ = (unsigned char)sym;
+                    *o++ = (T)sym;
                     if (s.in > in_end && overran(s, in_end)) return NEED_INPUT;
                     continue;
                 }
@@ -467,16 +484,17 @@ class BlockDecoder {
             drop(s, deb);
             if (s.in > in_end && overran(s, in_end)) return NEED_INPUT;
             if ((size_t)(o - out_begin) < distance) return BAD;
-            const unsigned char *src = o - distance;
-            unsigned char *const end = o + length;
+            const T *src = o - distance;
+            T *const end = o + length;
             if (distance >= 8) {
                 do {
-                    std::memcpy(o, src, 8);
+                    std::memcpy(o, src, 8 * sizeof(T));
                     o += 8;
                     src += 8;
                 } while (o < end);
             } else if (distance == 1) {
-                std::memset(o, *src, length);
+                if (sizeof(T) == 1) std::memset(o, (int)*src, length);
+                else std::fill_n(o, length, *src);
             } else {
                 do *o++ = *src++;
                 while (o < end);
@@ -491,6 +509,7 @@ class BlockDecoder {
     Long lit_long_, dist_long_, fixed_lit_long_, fixed_dist_long_;
     bool fixed_ready_ = false;
 };
+using BlockDecoder = BlockDecoderT<unsigned char>;
 
 // ---- one whole raw deflate stream in memory (a BGZF member's payload) -----------------------------------------------------
 // `in` must be readable for PAD bytes past in + n.  false: not a valid stream of exactly out_len bytes.
@@ -498,13 +517,42 @@ inline bool inflate_whole(BlockDecoder &dec, const unsigned char *in, size_t n, 
     BlockDecoder::Bits b;
     BlockDecoder::start(b, in);
     unsigned char *o = out, *const end = out + out_len;
-    // (the decoder wants 258 + 16 bytes of slack behind the write position: the caller's buffer has them, see Input::fill_bgzf)
+    // (the decoder wants SLACK bytes behind the write position: the caller's buffer has them, see Input::fill_bgzf)
     for (bool final = false; !final;) {
-        const Status st = dec.block(b, in + n, out, o, end + (258 + 16), final);
+        const Status st = dec.block(b, in + n, out, o, end + BlockDecoder::SLACK, final);
         if (st != OK) return false;
         if (o > end) return false;
     }
     return o == end;
+}
+
+// ---- a gzip member's header (RFC 1952 2.3) at p: OK and its length in `at`, NEED_INPUT when n bytes do not hold all of it, BAD
+// when it is none (bytes behind the last member that are no member -- zero padding, garbage -- are an error, as they are to the
+// reference's reader, flate2's MultiGzDecoder, and to the zlib path of this tool)
+inline Status gzip_header(const unsigned char *p, size_t n, size_t &at) {
+    if ((n > 0 && p[0] != 0x1F) || (n > 1 && p[1] != 0x8B)) return BAD;
+    if (n < 10) return NEED_INPUT;
+    if (p[2] != 8 || (p[3] & 0xE0)) return BAD;
+    const unsigned flg = p[3];
+    at = 10;
+    if (flg & 4) {  // FEXTRA
+        if (n < at + 2) return NEED_INPUT;
+        at += 2 + (p[at] | (size_t)p[at + 1] << 8);
+        if (n < at) return NEED_INPUT;
+    }
+    for (unsigned bit = 8; bit <= 16; bit <<= 1)  // FNAME, FCOMMENT: zero-terminated
+        if (flg & bit) {
+            const void *z = std::memchr(p + at, 0, n - at);
+            if (!z) return NEED_INPUT;
+            at = (size_t)((const unsigned char *)z - p) + 1;
+        }
+    if (flg & 2) {  // FHCRC: the low half of the CRC-32 of the header before it (checked, as zlib's inflate checks it)
+        if (n < at + 2) return NEED_INPUT;
+        const uint32_t want = p[at] | (uint32_t)p[at + 1] << 8;
+        if ((crc32_fast(0, p, at) & 0xFFFF) != want) return BAD;
+        at += 2;
+    }
+    return OK;
 }
 
 // ---- gzip members from a stream of bytes ------------------------------------------------------------------------------------
@@ -564,35 +612,10 @@ class GzReader {
             if (state_ == HEADER) {
                 const unsigned char *p = base + in_pos_, *e = base + in_end_;
                 if (p == e && eof_) return state_ = DONE, false;
-                // fixed part, then the optional fields named by FLG
-                size_t need = 10;
-                if ((p < e && p[0] != 0x1F) || (p + 1 < e && p[1] != 0x8B)) return fail("invalid gzip stream");
-                bool ok = (size_t)(e - p) >= need;
-                size_t at = 10;
-                if (ok) {
-                    // (bytes behind the last member that are no member -- zero padding, garbage -- are an error, as they are to
-                    // the reference's reader, flate2's MultiGzDecoder, and to the zlib path of this tool)
-                    if (p[0] != 0x1F || p[1] != 0x8B) return fail("invalid gzip stream");
-                    if (p[2] != 8 || (p[3] & 0xE0)) return fail("invalid gzip stream");
-                    const unsigned flg = p[3];
-                    if (flg & 4) {
-                        ok = (size_t)(e - p) >= at + 2;
-                        if (ok) {
-                            at += 2 + (p[at] | (size_t)p[at + 1] << 8);
-                            ok = (size_t)(e - p) >= at;
-                        }
-                    }
-                    for (unsigned bit = 8; ok && bit <= 16; bit <<= 1)  // FNAME, FCOMMENT: zero-terminated
-                        if (flg & bit) {
-                            const void *z = std::memchr(p + at, 0, (size_t)(e - p) - at);
-                            ok = z != nullptr;
-                            if (ok) at = (size_t)((const unsigned char *)z - p) + 1;
-                        }
-                    if (ok && (flg & 2)) {
-                        at += 2;
-                        ok = (size_t)(e - p) >= at;
-                    }
-                }
+                size_t at = 0;
+                const Status hs = gzip_header(p, (size_t)(e - p), at);
+                if (hs == BAD) return fail("invalid gzip stream");
+                const bool ok = hs == OK;
                 if (!ok) {
                     if (eof_) return fail("truncated gzip stream");
                     in_pos_ -= more_input(base + in_pos_);

@@ -1,5 +1,6 @@
-"""fast_inflate.hpp vs zlib on the GPU box: `deacon-hip cat --count` (input side alone) and `filter -d` end to end, on a gzip
-stream and a BGZF file of the same 4 M x 150 bp FASTQ, constant and random quality strings."""
+"""The tool's gzip readers on the GPU box: zlib, fast_inflate.hpp on one thread, parallel_gzip.hpp on 2..16 threads --
+`deacon-hip cat --count` (input side alone) and `filter -d` end to end, on a gzip stream and a BGZF file of the same
+4 M x 150 bp FASTQ, constant and random quality strings."""
 import gzip, os, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -32,18 +33,22 @@ for qual in ("const", "random"):
     files[qual] = len(fq)
     print(qual, "FASTQ %.2f GB -> gzip %.2f GB, bgzf %.2f GB" % (len(fq) / 1e9, os.path.getsize(f"{d}/{qual}.plain.fq.gz") / 1e9, os.path.getsize(f"{d}/{qual}.bgzf.fq.gz") / 1e9), flush=True)
     del fq, r
+WAYS = [("zlib", {"DCN_CLI_ZLIB_INFLATE": "1"}), ("one", {"DCN_CLI_NO_PARALLEL_GZ": "1"})] + [("par%d" % t, {"DCN_CLI_GZ_THREADS": str(t)}) for t in (2, 4, 8, 12, 16)] + [("default", {})]
 for rep in range(2):
     for qual in ("const", "random"):
         for name in ("plain", "bgzf"):
-            for env in ({}, {"DCN_CLI_ZLIB_INFLATE": "1"}):
+            for way, env in (WAYS if name == "plain" else [WAYS[0], WAYS[-1]]):
                 f = f"{d}/{qual}.{name}.fq.gz"
                 e = dict(os.environ, **env)
                 t = time.perf_counter()
-                p = subprocess.run([BIN, "cat", f, "--count"], capture_output=True, env=e)
+                p = subprocess.run([BIN, "cat", f, "--count"], capture_output=True, env=dict(e, DCN_CLI_GZ_STATS="1"))
+                stats = [l for l in p.stderr.decode().splitlines() if l.startswith("gzip reader:")]
                 dt_cat = time.perf_counter() - t
                 t = time.perf_counter()
                 q = subprocess.run([BIN, "filter", "-d", f"{d}/g.idx", f, "-o", f"{d}/out.fq", "-q"], capture_output=True, env=e)
                 dt = time.perf_counter() - t
-                print("%-6s %-5s %-5s cat %.2f s = %.2f GB/s of text | filter wall %.2f s = %.2f Gbp/s  rc %d %d out %d" % (
-                    qual, name, "zlib" if env else "fast", dt_cat, files[qual] / dt_cat / 1e9, dt, n * 150 / dt / 1e9, p.returncode, q.returncode, os.path.getsize(f"{d}/out.fq")), flush=True)
+                print("%-6s %-5s %-7s cat %.2f s = %.2f GB/s of text | filter wall %.2f s = %.2f Gbp/s  rc %d %d out %d" % (
+                    qual, name, way, dt_cat, files[qual] / dt_cat / 1e9, dt, n * 150 / dt / 1e9, p.returncode, q.returncode, os.path.getsize(f"{d}/out.fq")), flush=True)
+                if stats and rep == 0:
+                    print("        " + stats[0], flush=True)
 import shutil; shutil.rmtree(d)

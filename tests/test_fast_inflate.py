@@ -16,6 +16,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "deacon-server_amd", "bin", "deacon-hip")
 ZLIB = dict(os.environ, DCN_CLI_ZLIB_INFLATE="1")
+# the decoder three ways: one stream on several threads (parallel_gzip.hpp) with chunks so small that a test file is dozens of
+# them and single blocks are longer than a chunk's overlap; the same with the shipped chunk size; one thread (fast_inflate.hpp alone)
+SMALL_CHUNKS = dict(os.environ, DCN_CLI_GZ_THREADS="3", DCN_CLI_GZ_CHUNK="30000")
+ONE_THREAD = dict(os.environ, DCN_CLI_NO_PARALLEL_GZ="1")
+WAYS = {"small-chunks": SMALL_CHUNKS, "default": dict(os.environ, DCN_CLI_GZ_THREADS="4"), "one-thread": ONE_THREAD}
 
 
 def cat(blob, env=None, count=False):
@@ -80,23 +85,32 @@ def test_every_kind_of_block_decodes_to_zlibs_bytes(payloads):
             parts += [c.compress(data[i:i + 7777]), c.flush(zlib.Z_SYNC_FLUSH if i % 3 else zlib.Z_FULL_FLUSH)]
         blobs["flushed"] = b"".join(parts) + c.flush()
         for kind, blob in blobs.items():
-            rc, out, err = cat(blob)
-            assert rc == 0 and out == data, (name, kind, rc, len(out), len(data), err)
+            for way in ("small-chunks", "one-thread"):
+                rc, out, err = cat(blob, env=WAYS[way])
+                assert rc == 0 and out == data, (name, kind, way, rc, len(out), len(data), err)
 
 
 def test_members_header_fields_and_padding(payloads):
     fq = payloads["fastq"]
     blob = (member(fq[:100_000], 8, name=b"a.fq") + member(b"") +
             member(fq[100_000:300_000], 4 | 8 | 16 | 2, extra=b"XY\x03\x00abc", name=b"n", comment=b"c", level=1) + member(fq[300_000:], level=9))
-    assert cat(blob)[:2] == (0, fq)
     assert cat(blob, env=ZLIB)[:2] == (0, fq)
     # a header longer than one read of the input (an extra field of 60 KB and a long name)
     big = member(fq[:50_000], 4 | 8, extra=b"ZZ" + struct.pack("<H", 60_000) + bytes(60_000), name=b"n" * 70_000)
-    assert cat(big + member(fq[50_000:]))[:2] == (0, fq)
-    # what follows the last member: zlib's reader refuses anything that is not a member; so does ours, with the same words
-    for tail in (bytes(100), b"garbage"):
-        a, b = cat(blob + tail), cat(blob + tail, env=ZLIB)
-        assert a[0] == b[0] == 1 and "invalid gzip stream" in a[2] and "invalid gzip stream" in b[2]
+    # many small members that are not BGZF (no length field): each ends inside some chunk
+    many = b"".join(member(fq[i:i + 40_000], level=1 + i % 9) for i in range(0, len(fq), 40_000))
+    for way, env in WAYS.items():
+        assert cat(blob, env=env)[:2] == (0, fq), way
+        assert cat(big + member(fq[50_000:]), env=env)[:2] == (0, fq), way
+        assert cat(many, env=env)[:2] == (0, fq), way
+        # a header field that lies about the header: FHCRC
+        lying = bytearray(member(fq[:1000], 2))
+        lying[10] ^= 1
+        assert cat(bytes(lying), env=env)[0] == 1, way
+        # what follows the last member: zlib's reader refuses anything that is not a member; so does ours, with the same words
+        for tail in (bytes(100), b"garbage"):
+            a, b = cat(blob + tail, env=env), cat(blob + tail, env=ZLIB)
+            assert a[0] == b[0] == 1 and "invalid gzip stream" in a[2] and "invalid gzip stream" in b[2], way
 
 
 def test_large_input_crosses_the_decoders_buffers(payloads):
@@ -105,10 +119,12 @@ def test_large_input_crosses_the_decoders_buffers(payloads):
     data = payloads["fastq-quals"] * 12 + payloads["random"] * 3 + payloads["text"] * 4
     for lv in (1, 6):
         blob = gzip.compress(data, lv)
-        rc, out, err = cat(blob)
-        assert rc == 0 and out == data, (lv, err)
-    # stored blocks only, larger than the input buffer in total
-    assert cat(gzip.compress(data[:20_000_000], 0))[1] == data[:20_000_000]
+        for way, env in WAYS.items():
+            rc, out, err = cat(blob, env=env)
+            assert rc == 0 and out == data, (lv, way, err)
+    # stored blocks only, larger than the input buffer in total (nothing for the block search to find: the driver decodes alone)
+    for way, env in WAYS.items():
+        assert cat(gzip.compress(data[:20_000_000], 0), env=env)[1] == data[:20_000_000], way
     blob = gzip.compress(data[:6_000_000], 6)
     p = subprocess.Popen([BIN, "cat", "-"], stdin=subprocess.PIPE, stdout=subprocess.PIPE)
     import threading
@@ -128,10 +144,11 @@ def test_damaged_files_are_errors_never_other_bytes(payloads):
     fq = payloads["fastq"]
     blob = gzip.compress(fq, 6)
     for cut in (1, 5, 12, 1000, len(blob) // 2, len(blob) - 9, len(blob) - 3):
-        rc, out, err = cat(blob[:cut], count=True)
-        if cut < 2:
-            continue  # (a byte that is not a gzip magic is plain text to the tool)
-        assert rc == 1 and "gzip stream" in err, (cut, rc, err)
+        for way, env in WAYS.items():
+            rc, out, err = cat(blob[:cut], count=True, env=env)
+            if cut < 2:
+                continue  # (a byte that is not a gzip magic is plain text to the tool)
+            assert rc == 1 and "truncated gzip stream" in err, (cut, way, rc, err)
     random.seed(3)
     light = gzip.compress(fq[:300_000], 1)
     accepted = 0
@@ -140,7 +157,7 @@ def test_damaged_files_are_errors_never_other_bytes(payloads):
         for _ in range(random.randint(1, 4)):
             i = random.randrange(10, len(b))
             b[i] ^= 1 << random.randrange(8)
-        rc, out, err = cat(bytes(b))
+        rc, out, err = cat(bytes(b), env=SMALL_CHUNKS if t % 4 < 2 else ONE_THREAD)
         assert rc in (0, 1), (t, rc, err)  # never a signal
         if rc == 0:  # (rare: the flips cancelled out or hit a header field nobody checks) -- then zlib reads the same bytes
             accepted += 1
@@ -173,4 +190,16 @@ def test_decoder_stays_inside_its_buffers_under_the_sanitizers(tmp_path):
                     "-I", os.path.join(ROOT, "deacon-server_amd", "cli"), "-o", str(exe),
                     os.path.join(ROOT, "tests", "cpp", "fast_inflate_test.cpp"), "-lz"], check=True)
     p = subprocess.run([str(exe)], capture_output=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith(b"bad 0"), (p.stdout[-500:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("sanitizer,rounds", [("address,undefined", 36), ("thread", 10)])
+def test_parallel_reader_under_the_sanitizers(tmp_path, sanitizer, rounds):
+    """tests/cpp/parallel_gzip_test.cpp: one stream on 2-4 threads with 20 KB and 150 KB chunks, whole / cut short / damaged,
+    under AddressSanitizer + UBSan and under ThreadSanitizer (CPU builds: the reader is host code)"""
+    exe = tmp_path / "parallel_gzip_test"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "deacon-server_amd", "cli"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "cpp", "parallel_gzip_test.cpp"), "-lz"], check=True)
+    p = subprocess.run([str(exe), str(rounds)], capture_output=True)
     assert p.returncode == 0 and p.stdout.strip().endswith(b"bad 0"), (p.stdout[-500:], p.stderr[-3000:])

@@ -22,7 +22,7 @@ value = whole-job Mbp/s of that workload, plus
 and one scalar per extra leg measured at N = 1 after the timed region (none of it enters `value`):
   legs.{long,paired,union950m,...}           BASELINE configs[2], [3], [4]-sized table: Mbp/s + the oracle check
   host_path.{pageable,pinned,packed}         the PCIe-inclusive rate of dcn_filter_batch* from host memory
-  cli.{search50,deplete95,paired}            `deacon-hip filter` file to file
+  cli.{search50,deplete95,deplete95_gz,paired} `deacon-hip filter` file to file (deplete95_gz: from one gzip stream)
 Everything else that is measured (per-stage times, repetitions, counters, samples checked) goes to bench_detail.json next
 to this file (--detail PATH) and, as one line, to stderr.
 """

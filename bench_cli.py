@@ -145,6 +145,40 @@ def filter_run(idx_path, inputs, out_paths, extra, summary_path):
 
 
 # ---- (a) plumbing: SURVEY.md 8d config 1 at its stated shape -------------------------------------------------------------
+def gzip_one_member(src, dst, nbytes, threads, level=1, piece=16 << 20):
+    """the first nbytes of src as ONE gzip member (one deflate stream, what `gzip` / `pigz` write -- not BGZF), compressed
+    piece by piece on `threads` threads the way pigz does it: every piece but the last ends in a full flush (an empty stored
+    block at a byte boundary), the raw pieces follow each other, the trailer carries the CRC-32 of the whole"""
+    import mmap
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+    with open(src, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        view = memoryview(mm)[:nbytes]
+        spans = [(a, min(a + piece, nbytes)) for a in range(0, nbytes, piece)]
+
+        def deflate(i):
+            a, b = spans[i]
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            return c.compress(view[a:b]) + c.flush(zlib.Z_FINISH if i == len(spans) - 1 else zlib.Z_FULL_FLUSH)
+
+        def crc_all():
+            crc = 0
+            for a, b in spans:
+                crc = zlib.crc32(view[a:b], crc)
+            return crc
+        with ThreadPoolExecutor(max(2, threads)) as ex:  # (zlib releases the GIL)
+            crc_f = ex.submit(crc_all)
+            parts = list(ex.map(deflate, range(len(spans))))
+            crc = crc_f.result()
+        with open(dst, "wb") as o:
+            o.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\xff")
+            for p_ in parts:
+                o.write(p_)
+            o.write(struct.pack("<II", crc & 0xFFFFFFFF, nbytes & 0xFFFFFFFF))
+        del view
+
+
 def ecoli_shaped_inputs(d, n_reads=10_000):
     """genome (seed 1) as 80-column FASTA, reads (seed 2) as FASTQ; returns (genome bytes, (n, 150) reads, paths)"""
     alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -306,6 +340,25 @@ def file_to_file(index, genome_dev, host_keys_sorted, n_rand, make_reads, make_p
                 r[f"threads_{nt}"] = {k_: rt[k_] for k_ in ("args", "run_wall_s", "index_load_s", "Mbp_per_s_incl_index_load",
                                                                "Mbp_per_s_filter_only", "busy_core_s", "decisions_match") if k_ in rt}
                 r["decisions_match"] = r["decisions_match"] and rt["decisions_match"]
+                os.unlink(o2)
+            n_gz = min(n, (sizes.get("deplete95_gz", 8_000_000) if name == "deplete95" else 0))
+            if n_gz:
+                # the same reads from ONE gzip stream (what a .fastq.gz from a sequencing run is; not BGZF): the tool's own inflate
+                # on several threads (cli/parallel_gzip.hpp) in front of the same pipeline
+                gz, o2 = fq + ".gz", os.path.join(d, f"{name}.out_gz.fq")
+                t = time.perf_counter()
+                gzip_one_member(fq, gz, n_gz * REC, cores)
+                gz_s = time.perf_counter() - t
+                rg = filter_run(idx_path, [gz], [o2], extra, os.path.join(d, "s.json"))
+                rg["workload"] = (f"the first {n_gz:,} reads of deplete95 as one gzip member ({os.path.getsize(gz) / 1e9:.2f} GB, level 1, "
+                                  f"compressed in {gz_s:.1f} s), same arguments")
+                nchk_g = min(check_reads, n_gz)
+                rg["decisions_match"] = check(first["seqs"][:nchk_g], None, deplete, o2, nchk_g)
+                rg["checked"] = r["checked"]
+                out[name + "_gz"] = rg
+                log(f"cli.{name}_gz: run() {rg['run_wall_s']:.2f} s, {rg['Mbp_per_s_incl_index_load'] / 1e3:.2f} Gbp/s incl. index load, "
+                    f"{rg['Mbp_per_s_filter_only'] / 1e3:.2f} Gbp/s filter only, oracle ok={rg['decisions_match']}")
+                os.unlink(gz)
                 os.unlink(o2)
             out[name] = r
             log(f"cli.{name}: run() {r['run_wall_s']:.2f} s, {r['Mbp_per_s_incl_index_load'] / 1e3:.2f} Gbp/s incl. index load "

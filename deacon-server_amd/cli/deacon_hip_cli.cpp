@@ -127,6 +127,7 @@ class Input {
         }
     }
     ~Input() {
+        pgz_.reset();  // (its driver thread reads fd_: gone before the descriptor is)
         if (kind_ == GZIP) inflateEnd(&zs_);
         if (kind_ == ZSTD && zds_) zstd_->freeDStream(zds_);
         if (kind_ == XZ) lzma_->end(&ls_);

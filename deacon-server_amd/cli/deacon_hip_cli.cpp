@@ -666,9 +666,13 @@ struct Batch {
     uint64_t out_off2 = 0, out_bytes2 = 0;  // ... and the second mates', when they have a mapped file of their own (-O)
     size_t raw_end = 0;     // chunk reader: `text` holds raw input, whole records in [0, raw_end) ...
     bool raw_fastq = false;  // ... of this format
+    std::vector<char> text2;  // two streams of mates through the chunk readers: the second file's chunk, the same number of
+    size_t raw_end2 = 0;      // records in [0, raw_end2) ...
+    size_t n_records = 0;     // ... namely this many
     bool paired = false;
     void clear() {
         text.clear();
+        text2.clear();
         bases.clear();
         packed.clear();
         invmask.clear();
@@ -698,6 +702,8 @@ struct Batch {
         out_off = out_bytes = 0;
         out_off2 = out_bytes2 = 0;
         raw_end = 0;
+        raw_end2 = 0;
+        n_records = 0;
         raw_fastq = false;
         paired = false;
     }
@@ -1379,7 +1385,7 @@ size_t count_mapped_records(const char *d, size_t a, size_t b, bool fastq) {
 }
 
 // position behind the first `skip` records at or after a (a is a record start or a blank line)
-size_t skip_mapped_records(const char *d, size_t a, size_t size, bool fastq, size_t skip) {
+size_t skip_mapped_records(const char *d, size_t a, size_t size, bool fastq, size_t skip, size_t *left = nullptr) {
     size_t nb = 0, p = a;
     Rec r;
     while (skip && p < size) {
@@ -1391,6 +1397,7 @@ size_t skip_mapped_records(const char *d, size_t a, size_t size, bool fastq, siz
                        : parse_mapped_record<false, 0>(d, p, size, fastq, nullptr, nb, r, 0);
         --skip;
     }
+    if (left) *left = skip;  // records still wanted when [a, size) ran out
     return p;
 }
 
@@ -1987,14 +1994,18 @@ int run_filter(const FilterArgs &a_in) {
     if (parallel_in && mapped.data[0] != '@' && mapped.data[0] != '>') die("Invalid FASTX record start: expected '>' or '@'");
     // one stream that is not a mappable plain file (stdin, gzip / zstd / xz): the chunk reader below
     const bool chunk_in = !paired && !parallel_in && !std::getenv("DCN_CLI_NO_CHUNK_READER");
-    const bool pool_in = parallel_in || chunk_in || pair_in;  // batches come out of the parser pool
+    // two streams of mates of which at least one is not a mappable plain file (.fastq.gz pairs: the usual shape of a short-read
+    // run): two chunk readers in step, see below
+    const bool pair_chunk_in = paired && !paired_stdin && !pair_in && a.input != "-" && a.input2 != "-" && !std::getenv("DCN_CLI_NO_CHUNK_READER");
+    const bool pool_in = parallel_in || chunk_in || pair_in || pair_chunk_in;  // batches come out of the parser pool
     // the chunk parsers write the batch stream 2-bit packed (no ASCII copy of the bases, no second pass of the library's
     // host threads over it); --debug prints k-mer strings and wants the ASCII
     const bool packed_parse = pool_in && cli_can_pack() && !a.debug;
     BatchPool pool;
     Queue<std::unique_ptr<Batch>> parsed(4);
     std::unique_ptr<OrderedStage> parse_stage;
-    std::thread reader;
+    std::thread reader, reader2;
+    Queue<std::unique_ptr<Batch>> half_read(4);  // (pair_chunk_in: batches that hold file 1's chunk and wait for file 2's)
     if (parallel_in) {
         const char *d = mapped.data;
         size_t size = mapped.size;
@@ -2073,6 +2084,113 @@ int run_filter(const FilterArgs &a_in) {
                 b->out_bytes = at2[j + 1];
                 parse_stage->push(std::move(b));
             }
+            parse_stage->finish();
+        });
+    } else if (pair_chunk_in) {
+        // Two streams of mates, at least one of them compressed (or otherwise not mappable).  The record reader below walks both
+        // record by record on one thread (2.5 GB/s of FASTQ for the two together); the streams' own readers deliver 4+ GB/s
+        // EACH since the gzip reader runs on several threads.  So: one thread per stream.  The first cuts its stream into chunks
+        // of whole records, as the chunk reader of a single stream does, and counts each chunk's records (the parser's walk
+        // without the sequence copies); the second takes from its stream exactly that many records for the same batch; the
+        // parser pool then parses the two chunks into one batch of interleaved mates (parse_mapped_pairs, the parser of the
+        // mapped pair path: its two ranges need not be mappings).
+        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 4, [packed_parse, &t_parse](Batch &b) {
+            StageClock::Scope sc(t_parse);
+            b.offsets.assign(1, 0);
+            parse_mapped_pairs(b.text.data(), 0, b.raw_end, b.text2.data(), 0, b.raw_end2, b.raw_fastq, b, packed_parse);
+        }));
+        size_t chunk = 12u << 20;
+        if (const char *e = std::getenv("DCN_CLI_CHUNK_MB")) chunk = (size_t)std::max(1, std::atoi(e)) << 20;  // tuning / test hook
+        reader = std::thread([&, chunk] {
+            Input in(a.input);
+            std::vector<char> carry;
+            bool eof = false;
+            int fastq = -1;
+            while (!eof || !carry.empty()) {
+                std::unique_ptr<Batch> b = pool.get();
+                std::vector<char> &t = b->text;
+                t.resize(std::max(chunk, 2 * carry.size()));
+                std::memcpy(t.data(), carry.data(), carry.size());
+                size_t n = carry.size();
+                carry.clear();
+                size_t cut = 0;
+                for (;;) {
+                    while (n < t.size() && !eof) {
+                        const size_t got = in.read(t.data() + n, t.size() - n);
+                        if (got == 0) eof = true;
+                        n += got;
+                    }
+                    if (fastq < 0 && n) {
+                        size_t f = 0;
+                        while (f < n && (t[f] == '\n' || t[f] == '\r')) ++f;
+                        if (f < n) {
+                            if (t[f] != '@' && t[f] != '>') die("Invalid FASTX record start: expected '>' or '@'");
+                            fastq = t[f] == '@';
+                        }
+                    }
+                    cut = eof ? n : last_record_boundary(t.data(), n, fastq > 0);
+                    if (cut || eof) break;
+                    t.resize(2 * t.size());  // a record longer than the chunk
+                }
+                if (n == 0) break;
+                carry.assign(t.begin() + cut, t.begin() + n);
+                b->raw_end = cut;
+                b->raw_fastq = fastq > 0;
+                b->n_records = count_mapped_records(t.data(), 0, cut, fastq > 0);
+                if (b->n_records) half_read.push(std::move(b));
+            }
+            half_read.finish();
+        });
+        reader2 = std::thread([&, chunk] {
+            Input in(a.input2);
+            std::vector<char> carry;
+            bool eof = false;
+            int fastq = -1;
+            auto only_blank = [](const char *p, size_t n) {
+                for (size_t i = 0; i < n; ++i)
+                    if (p[i] != '\n' && p[i] != '\r') return false;
+                return true;
+            };
+            std::unique_ptr<Batch> b;
+            while (half_read.pop(b)) {
+                std::vector<char> &t = b->text2;
+                // (as many bytes as the first file's chunk is a good guess; what is read beyond the records wanted is carried over)
+                t.resize(std::max<size_t>(std::max(b->raw_end + (256u << 10), 2 * carry.size()), 1u << 20));
+                std::memcpy(t.data(), carry.data(), carry.size());
+                size_t n = carry.size(), p = 0, need = b->n_records;
+                carry.clear();
+                for (bool first = true;; first = false) {
+                    // more input: the whole guess at first, then a megabyte at a time
+                    const size_t want = first ? t.size() : std::min<size_t>(t.size(), n + (1u << 20));
+                    while (n < want && !eof) {
+                        const size_t got = in.read(t.data() + n, want - n);
+                        if (got == 0) eof = true;
+                        n += got;
+                    }
+                    if (fastq < 0 && n) {
+                        size_t f = 0;
+                        while (f < n && (t[f] == '\n' || t[f] == '\r')) ++f;
+                        if (f < n) {
+                            if (t[f] != '@' && t[f] != '>') die("Invalid FASTX record start: expected '>' or '@'");
+                            fastq = t[f] == '@';
+                            if ((fastq > 0) != b->raw_fastq) die("The two inputs are not of the same format (FASTA and FASTQ)");
+                        }
+                    }
+                    const size_t whole = eof ? n : (fastq < 0 ? 0 : last_record_boundary(t.data(), n, fastq > 0));
+                    if (whole > p) p = skip_mapped_records(t.data(), p, whole, fastq > 0, need, &need);
+                    if (need == 0) break;
+                    if (eof) die("Paired input ended with an unpaired record");
+                    if (n == t.size()) t.resize(t.size() + std::max<size_t>(t.size() / 2, 1u << 20));
+                }
+                carry.assign(t.begin() + p, t.begin() + n);
+                b->raw_end2 = p;
+                parse_stage->push(std::move(b));
+            }
+            // the first file has ended: so must the second
+            bool more = !only_blank(carry.data(), carry.size());
+            std::vector<char> rest(1u << 16);
+            for (size_t got; !more && !eof && (got = in.read(rest.data(), rest.size())) > 0;) more = !only_blank(rest.data(), got);
+            if (more) die("Second input has more records than the first");
             parse_stage->finish();
         });
     } else if (chunk_in) {
@@ -2400,6 +2518,7 @@ int run_filter(const FilterArgs &a_in) {
     }
     feeder.join();
     reader.join();
+    if (reader2.joinable()) reader2.join();
     writer.join();
     m_written = std::chrono::duration<double>(clock::now() - start).count();
     if (map_out) mapped_out.finish(out_bytes_total);

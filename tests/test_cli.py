@@ -833,6 +833,71 @@ def test_paired_files_in_parallel_match_the_record_reader(tmp_path, monkeypatch)
     assert p.returncode != 0 and b"more records" in p.stderr
 
 
+@gpu
+def test_paired_compressed_files_go_through_two_chunk_readers(tmp_path, monkeypatch):
+    """R1.fastq.gz + R2.fastq.gz -- the usual shape of a short-read run: each stream has a reader thread of its own that cuts
+    it into chunks of whole records; the second delivers exactly as many records per batch as the first counted, whatever
+    their bytes (ids of different lengths, mate 2 longer, CRLF in one file, blank lines).  The record-by-record reader
+    (DCN_CLI_NO_CHUNK_READER) must give the same bytes, for gzip + BGZF, plain + gzip, gzip + plain, and chunks far smaller
+    and far larger than the files."""
+    rng = np.random.default_rng(78)
+    genome = random_reads(rng, 1, 40_000, 40_000)[0]
+    idx = build_index(tmp_path, [("g", genome.decode())])
+    n = 24_000
+    l1, l2 = [], []
+    for i in range(n):
+        a, b = int(rng.integers(40, 100)), int(rng.integers(60, 160))
+        s = int(rng.integers(0, len(genome) - 200))
+        m1 = genome[s:s + a] if i % 2 else random_reads(rng, 1, a, a)[0]
+        m2 = genome[s + 20:s + 20 + b] if i % 2 else random_reads(rng, 1, b, b)[0]
+        l1.append(b"@p%d/1\n%s\n+\n%s\n" % (i, m1, b"I" * a) + (b"\n" if i % 5000 == 7 else b""))
+        l2.append(b"@pair-%d/2 extra\n%s\n+\n%s\n" % (i, m2, b"@" * b))
+    t1, t2 = b"".join(l1), b"".join(l2).replace(b"\n", b"\r\n")
+    (tmp_path / "r1.fq").write_bytes(t1)
+    (tmp_path / "r2.fq").write_bytes(t2)
+    (tmp_path / "r1.fq.gz").write_bytes(gzip.compress(t1, 4))
+    (tmp_path / "r2.fq.gz").write_bytes(gzip.compress(t2, 1))
+    (tmp_path / "r2.bgzf.fq.gz").write_bytes(bgzf_compress(t2))
+    want = {}
+    for extra in ([], ["-d"], ["-R"]):
+        monkeypatch.setenv("DCN_CLI_NO_CHUNK_READER", "1")
+        want[tuple(extra)] = run("filter", idx, tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz", "-t", 5, *extra).stdout
+        monkeypatch.delenv("DCN_CLI_NO_CHUNK_READER")
+        assert extra == ["-d"] or len(want[tuple(extra)]) > 100_000
+    for chunk_mb, gz_chunk in (("1", "40000"), ("64", None)):
+        monkeypatch.setenv("DCN_CLI_CHUNK_MB", chunk_mb)
+        if gz_chunk:
+            monkeypatch.setenv("DCN_CLI_GZ_CHUNK", gz_chunk)
+            monkeypatch.setenv("DCN_CLI_GZ_THREADS", "3")
+        for f1, f2 in (("r1.fq.gz", "r2.fq.gz"), ("r1.fq.gz", "r2.bgzf.fq.gz"), ("r1.fq", "r2.fq.gz"), ("r1.fq.gz", "r2.fq")):
+            for extra in ([], ["-d"], ["-R"]):
+                assert run("filter", idx, tmp_path / f1, tmp_path / f2, "-t", 5, *extra).stdout == want[tuple(extra)], (chunk_mb, f1, f2, extra)
+        # two output files: mate for mate
+        run("filter", idx, tmp_path / "r1.fq.gz", tmp_path / "r2.fq.gz", "-o", tmp_path / "o1.fq", "-O", tmp_path / "o2.fq.gz")
+        o1, o2 = (tmp_path / "o1.fq").read_bytes(), gzip.decompress((tmp_path / "o2.fq.gz").read_bytes())
+        assert o1.count(b"\n") == o2.count(b"\n") > 0
+        inter = want[()].split(b"\n")
+        assert o1.split(b"\n")[:4] == inter[:4] and o2.split(b"\n")[:4] == inter[4:8]
+        monkeypatch.delenv("DCN_CLI_GZ_CHUNK", raising=False)
+        monkeypatch.delenv("DCN_CLI_GZ_THREADS", raising=False)
+    monkeypatch.setenv("DCN_CLI_CHUNK_MB", "1")
+    # a file of mates that ends early, or runs on, is an error (the same words as the record reader's)
+    (tmp_path / "short.fq.gz").write_bytes(gzip.compress(b"".join(l2[:-3]), 1))
+    p = run("filter", idx, tmp_path / "r1.fq.gz", tmp_path / "short.fq.gz", check=False)
+    assert p.returncode != 0 and b"unpaired" in p.stderr
+    (tmp_path / "long.fq.gz").write_bytes(gzip.compress(b"".join(l2 + l2[:2]), 1))
+    p = run("filter", idx, tmp_path / "r1.fq.gz", tmp_path / "long.fq.gz", check=False)
+    assert p.returncode != 0 and b"more records" in p.stderr
+    # FASTA mates (records of several lines)
+    fa1 = b"".join(b">a%d\n%s\n%s\n" % (i, genome[i * 7:i * 7 + 60], genome[i * 7 + 60:i * 7 + 90]) for i in range(3000))
+    fa2 = b"".join(b">b%d\n%s\n" % (i, genome[i * 7 + 100:i * 7 + 170]) for i in range(3000))
+    (tmp_path / "a.fa.gz").write_bytes(gzip.compress(fa1, 1))
+    (tmp_path / "b.fa.gz").write_bytes(gzip.compress(fa2, 1))
+    got = run("filter", idx, tmp_path / "a.fa.gz", tmp_path / "b.fa.gz", "-a", 1).stdout
+    monkeypatch.setenv("DCN_CLI_NO_CHUNK_READER", "1")
+    assert got == run("filter", idx, tmp_path / "a.fa.gz", tmp_path / "b.fa.gz", "-a", 1).stdout and got.count(b">") == 6000
+
+
 # ---- BASELINE.json configs[0] at its stated shape (SURVEY.md 8d config 1) ------------------------------------------------
 def test_fastq_record_helpers_round_trip(tmp_path):
     import bench_cli

@@ -105,7 +105,7 @@ class Input {
             fast_ = !std::getenv("DCN_CLI_ZLIB_INFLATE");
             if (fast_) {
                 // one stream on several threads (parallel_gzip.hpp) where there are threads to be had
-                size_t workers = std::min<size_t>(std::max<size_t>(1, usable_cpus() / 2), 8);
+                size_t workers = std::min<size_t>(std::max<size_t>(1, usable_cpus() / 2), 16);  // (8 on a 16-CPU share; quality strings with many values want the 16)
                 if (const char *e = std::getenv("DCN_CLI_GZ_THREADS")) workers = (size_t)std::max(1, std::atoi(e));
                 size_t chunk = 2u << 20;  // (test hook: small chunks put every path of the reader to work on small files)
                 if (const char *e = std::getenv("DCN_CLI_GZ_CHUNK")) chunk = (size_t)std::max(4096, std::atoi(e));
@@ -289,7 +289,7 @@ class Input {
             return false;
         }
         bz_out_.resize(out_total);
-        size_t nthreads = std::min<size_t>(std::max<size_t>(1, usable_cpus() / 2), 8);
+        size_t nthreads = std::min<size_t>(std::max<size_t>(1, usable_cpus() / 2), 16);
         if (const char *e = std::getenv("DCN_CLI_BGZF_THREADS")) nthreads = (size_t)std::max(1, std::atoi(e));
         nthreads = std::min(nthreads, blks.size());
         std::atomic<size_t> next{0};

@@ -1,4 +1,4 @@
-// codecs.hpp -- zstd and xz streams for the command-line driver (get_writer, src/local_filter.rs:110-151; niffler's
+// codecs.hpp -- zstd, xz and bzip2 streams for the command-line driver (get_writer, src/local_filter.rs:110-151; niffler's
 // format sniffing on input, :41-55).  This image ships the RUNTIME libraries (libzstd.so.1, liblzma.so.5) but not
 // their headers, so the few entry points used are declared here exactly as the libraries' stable C ABIs define them
 // and bound with dlopen when a .zst / .xz stream is first met; a machine without the library gets a clear error
@@ -117,6 +117,50 @@ struct Lzma {
     }
 };
 
+// ---- bzip2 1.0 (bzlib.h): input only -- the reference's reader sniffs it too (niffler's default formats), its writer has no
+// such extension (get_writer, src/local_filter.rs:110-151)
+struct bz_stream {
+    char *next_in;
+    unsigned int avail_in, total_in_lo32, total_in_hi32;
+    char *next_out;
+    unsigned int avail_out, total_out_lo32, total_out_hi32;
+    void *state;
+    void *(*bzalloc)(void *, int, int);
+    void (*bzfree)(void *, void *);
+    void *opaque;
+};
+enum { BZ_OK = 0, BZ_STREAM_END = 4 };
+struct Bz2 {
+    int (*decompress_init)(bz_stream *, int verbosity, int small);
+    int (*decompress)(bz_stream *);
+    int (*decompress_end)(bz_stream *);
+    static const Bz2 *get(std::string *err) {
+        static Bz2 api;
+        static int state = 0;
+        static std::string why;
+        if (state == 0) {
+            void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libbz2.so", RTLD_NOW | RTLD_LOCAL);
+            auto sym = [&](const char *n) {
+                void *p = h ? dlsym(h, n) : nullptr;
+                if (!p && why.empty()) why = h ? std::string("libbz2 has no ") + n : std::string("libbz2.so.1.0 not found");
+                return p;
+            };
+            api.decompress_init = (int (*)(bz_stream *, int, int))sym("BZ2_bzDecompressInit");
+            api.decompress = (int (*)(bz_stream *))sym("BZ2_bzDecompress");
+            api.decompress_end = (int (*)(bz_stream *))sym("BZ2_bzDecompressEnd");
+            state = why.empty() ? 1 : -1;
+        }
+        if (state < 0) {
+            if (err) *err = why;
+            return nullptr;
+        }
+        return &api;
+    }
+};
+
+inline bool is_bz2_magic(const unsigned char *p, size_t n) { return n >= 4 && p[0] == 'B' && p[1] == 'Z' && p[2] == 'h' && p[3] >= '1' && p[3] <= '9'; }
 inline bool is_zstd_magic(const unsigned char *p, size_t n) { return n >= 4 && p[0] == 0x28 && p[1] == 0xB5 && p[2] == 0x2F && p[3] == 0xFD; }
 inline bool is_xz_magic(const unsigned char *p, size_t n) {
     return n >= 6 && p[0] == 0xFD && p[1] == '7' && p[2] == 'z' && p[3] == 'X' && p[4] == 'Z' && p[5] == 0x00;

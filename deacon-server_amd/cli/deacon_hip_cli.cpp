@@ -118,6 +118,12 @@ class Input {
             if (!zstd_) die("zstd input " + path + ": " + why);
             zds_ = zstd_->createDStream();
             if (!zds_ || zstd_->isError(zstd_->initDStream(zds_))) die("zstd initialisation failed");
+        } else if (codecs::is_bz2_magic(m, n)) {
+            kind_ = BZ2;
+            bz2_ = codecs::Bz2::get(&why);
+            if (!bz2_) die("bzip2 input " + path + ": " + why);
+            std::memset(&bs_, 0, sizeof bs_);
+            if (bz2_->decompress_init(&bs_, 0, 0) != codecs::BZ_OK) die("bzip2 initialisation failed");
         } else if (codecs::is_xz_magic(m, n)) {
             kind_ = XZ;
             lzma_ = codecs::Lzma::get(&why);
@@ -131,6 +137,7 @@ class Input {
         if (kind_ == GZIP) inflateEnd(&zs_);
         if (kind_ == ZSTD && zds_) zstd_->freeDStream(zds_);
         if (kind_ == XZ) lzma_->end(&ls_);
+        if (kind_ == BZ2) bz2_->decompress_end(&bs_);
         if (fd_ > 0) ::close(fd_);
     }
     size_t read(char *dst, size_t n) {
@@ -190,6 +197,26 @@ class Input {
                 pos_ += in.pos;
                 got += out.pos;
                 mid_stream_ = r != 0;  // 0: a frame just ended
+            } else if (kind_ == BZ2) {
+                if (!avail && raw_eof_) {
+                    if (mid_stream_) die("read error: truncated bzip2 stream");
+                    break;
+                }
+                bs_.next_in = raw_.data() + pos_;
+                bs_.avail_in = (unsigned)avail;
+                bs_.next_out = dst + got;
+                bs_.avail_out = (unsigned)std::min<size_t>(n - got, 1u << 30);
+                const unsigned out0 = bs_.avail_out;
+                const int r = bz2_->decompress(&bs_);
+                if (r != codecs::BZ_OK && r != codecs::BZ_STREAM_END) die("read error: invalid bzip2 stream");
+                pos_ += avail - bs_.avail_in;
+                got += out0 - bs_.avail_out;
+                mid_stream_ = r != codecs::BZ_STREAM_END;
+                if (r == codecs::BZ_STREAM_END) {  // the next stream of a concatenation (pbzip2, cat a.bz2 b.bz2)
+                    bz2_->decompress_end(&bs_);
+                    std::memset(&bs_, 0, sizeof bs_);
+                    if (bz2_->decompress_init(&bs_, 0, 0) != codecs::BZ_OK) die("bzip2 initialisation failed");
+                }
             } else {
                 ls_.next_in = (const uint8_t *)(raw_.data() + pos_);
                 ls_.avail_in = avail;
@@ -370,7 +397,7 @@ class Input {
             if (end_ >= 4096) break;  // enough to go on with; pipes deliver what they have
         }
     }
-    enum Kind { PLAIN, GZIP, ZSTD, XZ } kind_ = PLAIN;
+    enum Kind { PLAIN, GZIP, ZSTD, XZ, BZ2 } kind_ = PLAIN;
     int fd_ = -1;
     std::vector<char> raw_;
     size_t pos_ = 0, end_ = 0;
@@ -387,6 +414,8 @@ class Input {
     void *zds_ = nullptr;
     const codecs::Lzma *lzma_ = nullptr;
     codecs::lzma_stream ls_;
+    const codecs::Bz2 *bz2_ = nullptr;
+    codecs::bz_stream bs_;
 };
 
 // ---- output: plain, gzip, zstd or xz by extension (get_writer, src/local_filter.rs:110-151) ---------------------------
@@ -1011,7 +1040,7 @@ struct MappedFile {
         data = (const char *)p;
         size = (size_t)st.st_size;
         const unsigned char *m = (const unsigned char *)data;
-        if (codecs::is_gzip_magic(m, size) || codecs::is_zstd_magic(m, size) || codecs::is_xz_magic(m, size)) {  // compressed: the streaming reader
+        if (codecs::is_gzip_magic(m, size) || codecs::is_zstd_magic(m, size) || codecs::is_xz_magic(m, size) || codecs::is_bz2_magic(m, size)) {  // compressed: the streaming reader
             munmap(p, size);
             data = nullptr;
             return false;

@@ -113,6 +113,25 @@ def test_blocked_gzip_input_is_inflated_member_by_member(tmp_path):
         assert p.returncode == 1 and b"gzip stream" in p.stderr
 
 
+def test_bzip2_input_is_read_like_the_references_reader_reads_it(tmp_path):
+    """the reference's reader sniffs bzip2 too (niffler's default formats; README documents gz / zst / xz): one stream, a
+    concatenation of streams (pbzip2, `cat a.bz2 b.bz2`), stdin; a cut or damaged stream is an error (no GPU: `cat`)"""
+    import bz2
+    data = b"".join(b"@r%d\nACGTACGTACGGTTAACC\n+\nIIIIIIIIIIIIIIIIII\n" % i for i in range(60_000))
+    for name, blob in (("one", bz2.compress(data)), ("two", bz2.compress(data[:1_000_000]) + bz2.compress(data[1_000_000:], 1))):
+        f = tmp_path / f"{name}.fq.bz2"
+        f.write_bytes(blob)
+        assert run("cat", f).stdout == data, name
+        assert run("cat", "-", stdin=blob).stdout == data, name
+    whole = bz2.compress(data)
+    p = run("cat", "-", stdin=whole[:-20], check=False)
+    assert p.returncode == 1 and b"truncated bzip2 stream" in p.stderr
+    hurt = bytearray(whole)
+    hurt[len(hurt) // 2] ^= 0x10
+    p = run("cat", "-", stdin=bytes(hurt), check=False)
+    assert p.returncode == 1 and b"bzip2 stream" in p.stderr
+
+
 # ---- the reference's filter tests ------------------------------------------------------------------------------------
 gpu = pytest.mark.gpu
 

@@ -360,12 +360,23 @@ class ParallelGzReader {
                 for (unsigned v = 0; v < 256; ++v) lut[v] = (unsigned char)v;
                 std::memcpy(lut.get() + MARK, win, WINDOW);
 #if defined(__x86_64__)
-                const __m128i hi = _mm_set1_epi16((short)0xFF00);
+                const __m128i hi = _mm_set1_epi16((short)0xFF00), ramp = _mm_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7);
                 for (; i + 16 <= n; i += 16) {
                     const __m128i a = _mm_loadu_si128((const __m128i *)(in + i)), b = _mm_loadu_si128((const __m128i *)(in + i + 8));
                     if (_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_and_si128(_mm_or_si128(a, b), hi), _mm_setzero_si128())) == 0xFFFF) {
                         _mm_storeu_si128((__m128i *)(out + i), _mm_packus_epi16(a, b));
                         continue;
+                    }
+                    // sixteen markers in a row that name sixteen bytes in a row -- a match copied from before the start, which is
+                    // how markers come to be here at all (quality lines repeating the one above): sixteen bytes of the window
+                    const unsigned m0 = in[i];
+                    if (m0 >= MARK && m0 <= 0xFFFFu - 15) {
+                        const __m128i e0 = _mm_add_epi16(_mm_set1_epi16((short)m0), ramp);
+                        const __m128i e1 = _mm_add_epi16(e0, _mm_set1_epi16(8));
+                        if (_mm_movemask_epi8(_mm_and_si128(_mm_cmpeq_epi16(a, e0), _mm_cmpeq_epi16(b, e1))) == 0xFFFF) {
+                            _mm_storeu_si128((__m128i *)(out + i), _mm_loadu_si128((const __m128i *)(win + (m0 - MARK))));
+                            continue;
+                        }
                     }
                     for (size_t q = i; q < i + 16; ++q) out[q] = lut[in[q]];
                 }

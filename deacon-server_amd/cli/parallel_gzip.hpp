@@ -231,8 +231,10 @@ class ParallelGzReader {
     };
     Pool<uint16_t> sym_pool_;
     Pool<unsigned char> byte_pool_;
-    struct Stop {};
-    static uint64_t now_us() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }  // thrown inside the driver when the reader is being destroyed
+    struct Stop {};  // thrown inside the driver when the reader is being destroyed
+    static uint64_t now_us() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
 
     // ---- workers -------------------------------------------------------------------------------------------------------------
     void submit(std::function<void()> f, bool urgent) {

@@ -2022,7 +2022,8 @@ int run_filter(const FilterArgs &a_in) {
     bool fastq_in = parallel_in && mapped.data[0] == '@';
     if (parallel_in && mapped.data[0] != '@' && mapped.data[0] != '>') die("Invalid FASTX record start: expected '>' or '@'");
     // one stream that is not a mappable plain file (stdin, gzip / zstd / xz): the chunk reader below
-    const bool chunk_in = !paired && !parallel_in && !std::getenv("DCN_CLI_NO_CHUNK_READER");
+    // (... or interleaved mates on stdin: the same reader, chunks of an even number of records)
+    const bool chunk_in = (!paired || paired_stdin) && !parallel_in && !std::getenv("DCN_CLI_NO_CHUNK_READER");
     // two streams of mates of which at least one is not a mappable plain file (.fastq.gz pairs: the usual shape of a short-read
     // run): two chunk readers in step, see below
     const bool pair_chunk_in = paired && !paired_stdin && !pair_in && a.input != "-" && a.input2 != "-" && !std::getenv("DCN_CLI_NO_CHUNK_READER");
@@ -2226,10 +2227,15 @@ int run_filter(const FilterArgs &a_in) {
         // stdin or a compressed file, one stream: this thread only decompresses and cuts the stream into chunks of whole
         // records (each batch keeps its raw chunk: ids and qualities stay in it); the worker pool parses them with the
         // parser of the mapped path.  (One thread doing both ran at the parser's pace: ~1 GB/s against zstd's 1.5+.)
-        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 4, [packed_parse, &t_parse](Batch &b) {
+        parse_stage.reset(new OrderedStage(n_workers, 2 * n_workers + 4, [packed_parse, paired_stdin, &t_parse](Batch &b) {
             StageClock::Scope sc(t_parse);
             b.offsets.assign(1, 0);
             parse_mapped_chunk(b.text.data(), 0, b.raw_end, b.raw_fastq, b, packed_parse);
+            if (paired_stdin) {  // interleaved mates: records 2u and 2u + 1 are unit u (the reader cut an even number of them)
+                b.paired = true;
+                b.unit_id.resize(b.recs.size());
+                for (size_t i = 0; i < b.recs.size(); ++i) b.unit_id[i] = (uint32_t)(i / 2);
+            }
         }));
         reader = std::thread([&] {
             Input in(a.input);
@@ -2265,10 +2271,22 @@ int run_filter(const FilterArgs &a_in) {
                     t.resize(2 * t.size());  // a record longer than the chunk
                 }
                 if (n == 0) break;
+                if (paired_stdin) {
+                    // mates stay together: an odd record at the end of the chunk waits for its mate in the next one
+                    const size_t recs = count_mapped_records(t.data(), 0, cut, fastq > 0);
+                    if (recs & 1) {
+                        if (eof) die("Paired input ended with an unpaired record");
+                        cut = skip_mapped_records(t.data(), 0, cut, fastq > 0, recs - 1);
+                    }
+                    if (recs < 2 && !eof) {  // (one record longer than the chunk: read on)
+                        carry.assign(t.begin(), t.begin() + n);
+                        continue;
+                    }
+                }
                 carry.assign(t.begin() + cut, t.begin() + n);
                 b->raw_end = cut;
                 b->raw_fastq = fastq > 0;
-                parse_stage->push(std::move(b));
+                if (cut) parse_stage->push(std::move(b));
             }
             parse_stage->finish();
         });

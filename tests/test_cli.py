@@ -907,6 +907,16 @@ def test_paired_compressed_files_go_through_two_chunk_readers(tmp_path, monkeypa
     (tmp_path / "long.fq.gz").write_bytes(gzip.compress(b"".join(l2 + l2[:2]), 1))
     p = run("filter", idx, tmp_path / "r1.fq.gz", tmp_path / "long.fq.gz", check=False)
     assert p.returncode != 0 and b"more records" in p.stderr
+    # interleaved mates on stdin (plain and gzip): the chunk reader cuts an even number of records per chunk
+    inter = b"".join(a + b for a, b in zip(l1, l2))
+    for extra in ([], ["-d"], ["-R"]):
+        for blob in (inter, gzip.compress(inter, 1)):
+            assert run("filter", idx, "-", "-", "-t", 5, *extra, stdin=blob).stdout == want[tuple(extra)], extra
+    monkeypatch.setenv("DCN_CLI_NO_CHUNK_READER", "1")
+    assert run("filter", idx, "-", "-", "-t", 5, stdin=inter).stdout == want[()]
+    monkeypatch.delenv("DCN_CLI_NO_CHUNK_READER")
+    p = run("filter", idx, "-", "-", stdin=inter + l1[0], check=False)
+    assert p.returncode != 0 and b"unpaired" in p.stderr
     # FASTA mates (records of several lines)
     fa1 = b"".join(b">a%d\n%s\n%s\n" % (i, genome[i * 7:i * 7 + 60], genome[i * 7 + 60:i * 7 + 90]) for i in range(3000))
     fa2 = b"".join(b">b%d\n%s\n" % (i, genome[i * 7 + 100:i * 7 + 170]) for i in range(3000))

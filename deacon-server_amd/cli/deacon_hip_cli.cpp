@@ -49,6 +49,7 @@
 #include <vector>
 
 #include "codecs.hpp"
+#include "fast_deflate.hpp"
 #include "fast_inflate.hpp"
 #include "parallel_gzip.hpp"
 #include "deacon_hip.hpp"
@@ -465,6 +466,34 @@ class Output {
             // inflates it on several threads (Input::fill_bgzf).  Costs 26 bytes and a fresh window per 64 KB (~2-3 % of size).
             // DCN_CLI_GZIP_ONE_MEMBER=1 keeps the one member per batch of rounds 2-3.
             static const bool one_member = std::getenv("DCN_CLI_GZIP_ONE_MEMBER") != nullptr;
+            // levels 1-3 (the default is 2): the tool's own compressor (fast_deflate.hpp: 2-2.6 x zlib's pace at those levels
+            // and no larger); higher levels are zlib's longer searches.  DCN_CLI_ZLIB_DEFLATE=1: zlib for every level.
+            static const bool zlib_deflate = std::getenv("DCN_CLI_ZLIB_DEFLATE") != nullptr;
+            if (!one_member && level <= 3 && !zlib_deflate) {
+                static thread_local std::unique_ptr<fastgz::FastDeflate> enc;
+                if (!enc) enc.reset(new fastgz::FastDeflate());
+                constexpr size_t BLOCK = 65280;
+                out.reserve(n / 3 + (n / BLOCK + 1) * 32 + 64);
+                size_t pos = 0;
+                do {  // (n == 0: one empty member, which is BGZF's end-of-file marker)
+                    const size_t take = std::min(BLOCK, n - pos);
+                    const size_t at = out.size();
+                    out.resize(at + 18 + fastgz::FastDeflate::bound(take) + 8);
+                    unsigned char *h = (unsigned char *)out.data() + at;
+                    static const unsigned char head[16] = {0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 0xFF, 6, 0, 'B', 'C', 2, 0};
+                    std::memcpy(h, head, 16);
+                    const size_t clen = enc->compress((const unsigned char *)in + pos, take, h + 18), total = 18 + clen + 8;
+                    if (total > 65536) die("write error: gzip member too large");
+                    h[16] = (unsigned char)((total - 1) & 0xFF);
+                    h[17] = (unsigned char)((total - 1) >> 8);
+                    const uint32_t crc = fastgz::crc32_fast(0, (const unsigned char *)in + pos, take);
+                    unsigned char *t = h + 18 + clen;
+                    for (int i = 0; i < 4; ++i) t[i] = (unsigned char)(crc >> (8 * i)), t[4 + i] = (unsigned char)((uint32_t)take >> (8 * i));
+                    out.resize(at + total);
+                    pos += take;
+                } while (pos < n);
+                return;
+            }
             z_stream zs;
             std::memset(&zs, 0, sizeof zs);
             if (deflateInit2(&zs, level, Z_DEFLATED, one_member ? 15 + 16 : -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("gzip initialisation failed");
@@ -2846,6 +2875,28 @@ int main(int argc, char **argv) {
             }
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::fprintf(stderr, "decoded %llu bytes in %.3f s: %.2f GB/s\n", (unsigned long long)total, sec, total / sec / 1e9);
+            return 0;
+        }
+        if (args[0] == "gz" && args.size() >= 1) {  // hidden: the .gz writer alone (stdin -> BGZF members on stdout; no GPU): gz [level]
+            const int level = args.size() >= 2 ? std::atoi(args[1].c_str()) : 2;
+            std::vector<char> in, piece;
+            std::vector<char> buf(1u << 20);
+            for (ssize_t r; (r = ::read(0, buf.data(), buf.size())) > 0;) in.insert(in.end(), buf.begin(), buf.begin() + r);
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<char> all;
+            for (size_t pos = 0; pos < in.size(); pos += 8u << 20) {  // (a batch's worth per call, as the formatter threads make them)
+                Output::compress_member(Output::GZIP, level, in.data() + pos, std::min<size_t>(8u << 20, in.size() - pos), piece);
+                all.insert(all.end(), piece.begin(), piece.end());
+            }
+            Output::compress_member(Output::GZIP, level, "", 0, piece);  // the end-of-file member
+            all.insert(all.end(), piece.begin(), piece.end());
+            const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            for (size_t w = 0; w < all.size();) {
+                const ssize_t r = ::write(1, all.data() + w, all.size() - w);
+                if (r < 0) die("write error");
+                w += (size_t)r;
+            }
+            std::fprintf(stderr, "compressed %zu -> %zu bytes in %.3f s: %.0f MB/s on one thread\n", in.size(), all.size(), sec, in.size() / sec / 1e6);
             return 0;
         }
         if (args[0] == "bench-parse" && args.size() >= 2) {  // hidden: the parser pool alone on a plain FASTX file (no GPU)

@@ -139,10 +139,11 @@ class BlockDecoderT {
     Status block(Bits &b, const unsigned char *in_end, T *out_begin, T *&out, T *out_end, bool &final) {
         Bits s = b;
         T *o = out;
-        if (!need(s, in_end, 3)) return NEED_INPUT;
+        fill(s, 3);
         final = (s.buf & 1) != 0;
         const unsigned type = (unsigned)(s.buf >> 1) & 3;
         drop(s, 3);
+        if (overran(s, in_end)) return NEED_INPUT;
         Status st;
         if (type == 0) st = stored(s, in_end, o, out_end);
         else if (type == 1) {
@@ -152,6 +153,7 @@ class BlockDecoderT {
             st = dynamic_tables(s, in_end);
             if (st == OK) st = huffman(s, in_end, out_begin, o, out_end, lit_, dist_, lit_long_, dist_long_);
         } else st = BAD;
+        if (st == BAD && overran(s, in_end)) st = NEED_INPUT;  // (what was decoded came out of the padding)
         if (st != OK) return st;
         b = s;
         out = o;
@@ -188,12 +190,11 @@ class BlockDecoderT {
         s.buf >>= n;
         s.cnt -= n;
     }
-    // at least n (<= 56) bits in the buffer that lie inside the input; false: the input ends before them
-    static inline bool need(Bits &s, const unsigned char *in_end, unsigned n) {
+    // at least n (<= 56) bits in the buffer.  Whether they were bits of the input (and not of the padding behind it) is asked
+    // afterwards, of what was CONSUMED (overran): asking for n bits ahead of need would refuse a stream whose last symbols are
+    // shorter than the longest a lookup may see -- the last code lengths of a 15-byte member, say
+    static inline void fill(Bits &s, unsigned n) {
         if (s.cnt < n) refill(s);
-        // bits that really exist: those of bytes before in_end
-        const int64_t beyond = (int64_t)(s.in - in_end) * 8;  // bytes loaded past the end (may be negative)
-        return beyond <= 0 || (int64_t)s.cnt - beyond >= (int64_t)n;
     }
     static inline bool overran(const Bits &s, const unsigned char *in_end) {  // consumed bits that the input does not hold
         return (int64_t)(s.in - in_end) * 8 > (int64_t)s.cnt;
@@ -331,24 +332,26 @@ class BlockDecoderT {
     }
 
     Status dynamic_tables(Bits &s, const unsigned char *in_end) {
-        if (!need(s, in_end, 14)) return NEED_INPUT;
+        fill(s, 14);
         const int hlit = (int)(s.buf & 31) + 257, hdist = (int)((s.buf >> 5) & 31) + 1, hclen = (int)((s.buf >> 10) & 15) + 4;
         drop(s, 14);
         if (hlit > 286 || hdist > 30) return BAD;
         static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         uint8_t cl[19] = {0};
         for (int i = 0; i < hclen; ++i) {
-            if (!need(s, in_end, 3)) return NEED_INPUT;
+            fill(s, 3);
             cl[order[i]] = (uint8_t)(s.buf & 7);
             drop(s, 3);
         }
+        if (overran(s, in_end)) return NEED_INPUT;
         uint32_t ct[128];
         Long clong;
         if (!build_plain(cl, 19, 7, ct, clong)) return BAD;
         uint8_t lens[286 + 30 + 138];
         int i = 0;
         while (i < hlit + hdist) {
-            if (!need(s, in_end, 7 + 7)) return NEED_INPUT;
+            if (s.in > in_end && overran(s, in_end)) return NEED_INPUT;  // (never more than a symbol into the padding)
+            fill(s, 7 + 7);
             const uint32_t e = ct[s.buf & 127];
             const int l = (int)(e & 0xFF);
             if (l == 0) return BAD;

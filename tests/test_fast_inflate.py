@@ -175,6 +175,12 @@ def test_blocked_gzip_members_take_the_same_decoder(payloads):
         for env in (None, ZLIB, dict(os.environ, DCN_CLI_BGZF_THREADS="3")):
             rc, out, err = cat(blob, env=env)
             assert rc == 0 and out == data, (name, err)
+    # members of a few bytes: their last symbols are shorter than what one lookup may see (a decoder that asks for a lookup's
+    # worth of bits AHEAD of each symbol refuses them -- this one did, before the tool's own compressor showed it)
+    tiny = payloads["fastq"][:3000] + b"I" * 200
+    for block in (1, 7, 16, 33):
+        for env in (None, ZLIB):
+            assert cat(bgzf_compress(tiny, block=block), env=env)[:2] == (0, tiny), block
     # a member whose CRC or length field lies
     blob = bytearray(bgzf_compress(payloads["fastq"][:200_000]))
     first = (blob[16] | blob[17] << 8) + 1
@@ -202,4 +208,50 @@ def test_parallel_reader_under_the_sanitizers(tmp_path, sanitizer, rounds):
                     "-I", os.path.join(ROOT, "deacon-server_amd", "cli"), "-o", str(exe),
                     os.path.join(ROOT, "tests", "cpp", "parallel_gzip_test.cpp"), "-lz"], check=True)
     p = subprocess.run([str(exe), str(rounds)], capture_output=True)
+    assert p.returncode == 0 and p.stdout.strip().endswith(b"bad 0"), (p.stdout[-500:], p.stderr[-3000:])
+
+
+def gz_write(data, level=2, env=None):
+    """`deacon-hip gz [level]`: the .gz writer alone -- stdin to BGZF members on stdout, as the formatter threads write them"""
+    p = subprocess.run([BIN, "gz", str(level)], input=data, capture_output=True, env=env)
+    assert p.returncode == 0, p.stderr
+    return p.stdout
+
+
+def test_gz_writer_own_compressor_and_zlib(payloads):
+    """.gz outputs at levels 1-3 go through the tool's own compressor (cli/fast_deflate.hpp), 4+ and DCN_CLI_ZLIB_DEFLATE=1 through
+    zlib: either way python's gzip, zlib's inflate and the tool's own readers give the input back; the file is BGZF (every
+    member <= 64 KB with its size in the BC field, the empty member last); what does not compress is stored, not blown up; the
+    own compressor is not larger than zlib at the same level on FASTQ"""
+    from test_cli import bgzf_compress  # noqa: F401  (the same layout the reader tests write)
+    for name, data in payloads.items():
+        data = data[:3_000_000]
+        for level, env in ((1, None), (2, None), (3, None), (2, dict(os.environ, DCN_CLI_ZLIB_DEFLATE="1")), (5, None)):
+            blob = gz_write(data, level, env)
+            assert gzip.decompress(blob) == data, (name, level)
+            assert cat(blob)[:2] == (0, data), (name, level)
+            # members: header with the BC subfield, sizes that add up, the end-of-file member
+            at, n_members = 0, 0
+            while at < len(blob):
+                assert blob[at:at + 4] == b"\x1f\x8b\x08\x04" and blob[at + 12:at + 16] == b"BC\x02\x00", (name, at)
+                size = (blob[at + 16] | blob[at + 17] << 8) + 1
+                assert 26 <= size <= 65536
+                at += size
+                n_members += 1
+            # (bgzip / htslib know an untruncated file by these exact 28 bytes)
+            assert at == len(blob) and blob[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+            assert n_members == (len(data) + 65279) // 65280 + 1 or len(data) == 0
+            assert len(blob) <= len(data) + (34 if env is None and level <= 3 else 64) * n_members + 64, (name, level, len(blob), len(data))
+    fq = payloads["fastq-quals"]
+    assert len(gz_write(fq, 2)) <= len(gz_write(fq, 2, dict(os.environ, DCN_CLI_ZLIB_DEFLATE="1"))) * 1.01
+
+
+def test_compressor_under_the_sanitizers(tmp_path):
+    """tests/cpp/fast_deflate_test.cpp: 4,000 inputs of 0 ... 65,535 bytes through the compressor into buffers of exactly
+    bound(n) bytes, read back by zlib and by the tool's decoder, under AddressSanitizer + UBSan"""
+    exe = tmp_path / "fast_deflate_test"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I", os.path.join(ROOT, "deacon-server_amd", "cli"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "cpp", "fast_deflate_test.cpp"), "-lz"], check=True)
+    p = subprocess.run([str(exe)], capture_output=True)
     assert p.returncode == 0 and p.stdout.strip().endswith(b"bad 0"), (p.stdout[-500:], p.stderr[-3000:])

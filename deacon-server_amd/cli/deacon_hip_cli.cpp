@@ -1315,7 +1315,9 @@ inline size_t parse_mapped_record(const char *d, size_t p, size_t b, bool fastq,
         size_t s1 = e0 + 1, e1 = eol(s1), s2 = e1 + 1;
         size_t e2 = (s2 + 1 < b && d[s2 + 1] == '\n') ? s2 + 1 : eol(s2);
         size_t s3 = e2 + 1, e3 = eol(s3);
+        if (s1 >= b) die("Truncated FASTQ record");  // (the words of the record reader, FastxReader::next)
         if (s2 >= b || d[s2] != '+') die("Invalid FASTQ record: missing '+' line");
+        if (s3 >= b) die("Truncated FASTQ record");  // the input ends behind the '+' line: no quality line at all
         size_t t1 = trim(s1, e1), t3 = trim(s3, e3);
         if (t3 - s3 != t1 - s1) die("FASTQ sequence and quality lengths differ");
         if (MODE == 1) std::memcpy(bases + nb, d + s1, t1 - s1);  // sequence = quality length: at most half of the chunk's bytes
@@ -1997,6 +1999,8 @@ int run_filter(const FilterArgs &a_in) {
     // plain regular single input: mmap + parallel parsing of record-aligned chunks (see stage 1)
     MappedFile mapped, mapped2;
     bool parallel_in = !paired && a.input != "-" && mapped.open(a.input);
+    // (a file that begins with a blank line is read by the stream readers, which skip it as the reference's reader does)
+    if (parallel_in && mapped.size > 0 && (mapped.data[0] == '\n' || mapped.data[0] == '\r')) parallel_in = false;
     // two plain regular files of mates: both mapped, cut at the same record numbers, parsed in parallel as well
     const bool pair_in = paired && !paired_stdin && a.input != "-" && a.input2 != "-" && !std::getenv("DCN_CLI_NO_PAIR_MMAP") &&
                          mapped.open(a.input) && mapped2.open(a.input2) && mapped.size > 0 && mapped2.size > 0 &&

@@ -853,6 +853,36 @@ def test_paired_files_in_parallel_match_the_record_reader(tmp_path, monkeypatch)
 
 
 @gpu
+def test_malformed_inputs_get_the_same_answer_from_every_reader(tmp_path, monkeypatch):
+    """the mapped parser (plain file), the chunk reader (the same bytes gzip-compressed) and the record reader
+    (DCN_CLI_NO_CHUNK_READER): same exit code, same output, same last line of stderr for records cut short, quality strings of
+    the wrong length, a missing '+' line, garbage, blank lines, CRLF, an empty file, a file of blank lines"""
+    idx = build_index(tmp_path, [("g", SEQ1)])
+    good = "@r1\n" + SEQ1[:60] + "\n+\n" + "I" * 60 + "\n"
+    cases = {
+        "ok": good * 3, "no final newline": (good * 3)[:-1],
+        "last quality line missing": good * 2 + "@r3\nACGTACGT\n+\n",
+        "last record cut in the sequence": good * 2 + "@r3\nACGTAC",
+        "quality shorter": good + "@r2\nACGTACGTAC\n+\nIIII\n" + good, "quality longer": good + "@r2\nACGT\n+\nIIIIIIII\n" + good,
+        "no plus line": good + "@r2\nACGTACGT\nIIIIIIII\n" + good, "starts with garbage": "xyz\n" + good,
+        "garbage between records": good + "garbage\n" + good, "empty": "", "only newlines": "\n\n\n", "leading blank line": "\n" + good,
+        "fasta empty sequence": ">a\n>b\n" + SEQ1 + "\n", "crlf": (good * 2).replace("\n", "\r\n"), "blank lines between": good + "\n\n" + good,
+    }
+    for name, text in cases.items():
+        (tmp_path / "x.fq").write_bytes(text.encode())
+        (tmp_path / "x.fq.gz").write_bytes(gzip.compress(text.encode(), 1))
+        seen = set()
+        for path, env in (("x.fq", {}), ("x.fq.gz", {}), ("x.fq.gz", {"DCN_CLI_NO_CHUNK_READER": "1"})):
+            p = run("filter", idx, tmp_path / path, "-q", "-a", 1, check=False, env=dict(os.environ, **env))
+            err = p.stderr.decode().strip().splitlines()
+            seen.add((p.returncode, p.stdout, err[-1] if err else ""))
+        assert len(seen) == 1, (name, seen)
+        rc = next(iter(seen))[0]
+        assert (rc == 0) == (name in ("ok", "no final newline", "empty", "only newlines", "leading blank line", "fasta empty sequence", "crlf",
+                                      "blank lines between")), (name, seen)
+
+
+@gpu
 def test_paired_compressed_files_go_through_two_chunk_readers(tmp_path, monkeypatch):
     """R1.fastq.gz + R2.fastq.gz -- the usual shape of a short-read run: each stream has a reader thread of its own that cuts
     it into chunks of whole records; the second delivers exactly as many records per batch as the first counted, whatever

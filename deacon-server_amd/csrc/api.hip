@@ -370,6 +370,7 @@ struct dcn_slot {
     // and are widened into d_offsets by a kernel in front of each chunk's own kernels
     uint32_t *d_off32 = nullptr, *h_off32 = nullptr;
     bool off32 = false;
+    bool lean = false; // submitted on one stream, plain forms of everything (see submit_impl)
     // The invalid-base mask of a packed stream is a third of its bytes and almost all zero (a word per 32 bases, non-zero
     // only where a base is not ACGT): its non-zero words cross the link as (group, word) pairs, the rest is a memset on the
     // device.  A chunk whose pairs do not fit (one group in 16 non-zero, over the batch) goes whole.
@@ -459,6 +460,7 @@ struct dcn_ctx {
     uint8_t *d_dump_valid = nullptr;
     // deferred state of the last enqueued device-API batch
     bool batch_pending = false;
+    bool lean = false; // a small host batch is being submitted: copies and result copies go on `stream` itself (submit_impl)
     // optional per-stage timing: a ring of event sets, one per batch in flight
     static constexpr int PROF_RING = 64;
     int profiling = 0; // 0 off, 1 every stage, 2 the scan stage only (two events per run instead of six)
@@ -1619,6 +1621,7 @@ __global__ __launch_bounds__(256) void scatter_mask_kernel(const uint2 *__restri
 // The non-zero words of mask[0, m) (group g_base + i of the stream) appended to the slot's page-locked pair buffer, found by
 // the pool.  false: sparse form off, or no room left -- the caller sends the words whole.
 bool sparse_mask_pairs(dcn_slot &sl, const uint32_t *mask, uint64_t g_base, uint64_t m, dcn_mask_range *out) {
+    if (sl.lean) return false; // (a small batch: the mask words themselves are one short copy, the pairs a memset and a kernel more)
     if (getenv("DCN_NO_SPARSE_MASK") || g_base + m > 0xFFFFFFFFull) return false; // (read per chunk: tests switch it)
     if (ensure_pinned(&sl.h_mask_pairs, sl.mask_pairs_cap) != DCN_OK) return false;
     std::vector<std::vector<uint2>> found((size_t)std::max(1, HostPool::get().width()));
@@ -1705,7 +1708,7 @@ int chunk_events(dcn_slot &sl, size_t n) {
 // decisions then go back in one copy behind the last chunk)
 int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d, bool n_known = true, bool is_last = false) {
     const dcn_chunk &ch = sl.chunks[ci];
-    if (wait_h2d) DCN_HIP(hipStreamWaitEvent(c->stream, sl.ev_h2d[ci], 0));
+    if (wait_h2d && !c->lean) DCN_HIP(hipStreamWaitEvent(c->stream, sl.ev_h2d[ci], 0)); // (lean: the copies are on this stream)
     if (sl.off32) {
         const uint32_t n = ch.r1 - ch.r0 + 1;
         hipLaunchKernelGGL(widen_offsets_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 1024)), dim3(256), 0, c->stream,
@@ -1747,8 +1750,10 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d, bool n_kno
     const bool last = n_known ? ci + 1 == n_ch : is_last;
     const bool split = n_known && !sl.counts && n_ch >= 4, early = split && ci + 2 == n_ch;
     if (!sl.counts && !last && !early) return DCN_OK;
-    DCN_HIP(hipEventRecord(sl.ev_comp[ci], c->stream));
-    DCN_HIP(hipStreamWaitEvent(c->d2h_stream, sl.ev_comp[ci], 0));
+    if (!c->lean) { // (lean: d2h_stream IS the compute stream for this submission)
+        DCN_HIP(hipEventRecord(sl.ev_comp[ci], c->stream));
+        DCN_HIP(hipStreamWaitEvent(c->d2h_stream, sl.ev_comp[ci], 0));
+    }
     const uint32_t k0 = sl.counts ? ch.u0 : (split && last ? sl.chunks[n_ch - 2].u1 : 0u);
     const uint32_t nu = ch.u1 - k0;
     DCN_HIP(hipMemcpyAsync((sl.keep_direct ? sl.u_keep : sl.h_keep) + k0, sl.d_keep + k0, nu, hipMemcpyDeviceToHost,
@@ -1765,10 +1770,12 @@ int enqueue_chunk(dcn_ctx *c, dcn_slot &sl, size_t ci, bool wait_h2d, bool n_kno
 int finish_submission(dcn_ctx *c, dcn_slot &sl) {
     // the report is written on the compute stream (cleared at submission, filled by the finish kernels): the copy must
     // come behind all of it, also for a batch without any chunk
-    const int e = c->ev_next;
-    c->ev_next = (e + 1) % dcn_ctx::N_EV;
-    DCN_HIP(hipEventRecord(c->ev_comp[e], c->stream));
-    DCN_HIP(hipStreamWaitEvent(c->d2h_stream, c->ev_comp[e], 0));
+    if (!c->lean) {
+        const int e = c->ev_next;
+        c->ev_next = (e + 1) % dcn_ctx::N_EV;
+        DCN_HIP(hipEventRecord(c->ev_comp[e], c->stream));
+        DCN_HIP(hipStreamWaitEvent(c->d2h_stream, c->ev_comp[e], 0));
+    }
     DCN_HIP(hipMemcpyAsync(sl.h_report, sl.d_report, sizeof(dcn_batch_report), hipMemcpyDeviceToHost, c->d2h_stream));
     DCN_HIP(hipEventRecord(sl.done, c->d2h_stream));
     return DCN_OK;
@@ -1821,6 +1828,34 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     else if (pinned_dma) tr = Transport::AsciiDirect;
     else tr = host_pack_ok ? Transport::HostPacked : Transport::AsciiStaged;
 
+    // A SMALL batch is some twenty GPU commands -- copies, memsets, a handful of kernels, event records and waits between three
+    // streams -- whatever it carries, and those, not its kernels, are what it costs (130 us for 1,024 reads as for 16,384), and
+    // what several contexts calling at once queue up behind (eight threads: 1.2 Gbp/s at 1,024 reads per call, 17 at 16,384;
+    // profiles/r04_small_calls.txt).  Up to DCN_LEAN_MAX_BASES (16 Mbp; 0: never) a batch is submitted in its plain form on ONE
+    // stream: copies, kernels and result copies in order on `stream` (no events between streams; what a batch of this size
+    // could overlap inside itself is tens of microseconds), 64-bit offsets as they are (no narrowing and widening kernel), the
+    // mask words themselves (no pairs, memset and scatter kernel).  Same box: 1,024 reads per call 1.2 -> 1.5 Gbp/s from one
+    // thread and 1.2 -> 4.0 from eight, 16,384: 15 -> 18 and 17 -> 45, 65,536: 37 -> 40 and 52 -> 79; at 262,144 (39 Mbp) the
+    // three-stream form wins again (98 against 67 from two threads), hence the limit.
+    const char *lean_env = getenv("DCN_LEAN_MAX_BASES"); // (read per call: tests run both forms in one process)
+    const uint64_t lean_max_bases = lean_env ? strtoull(lean_env, nullptr, 10) : (16ull << 20);
+    struct LeanScope {
+        dcn_ctx *c;
+        hipStream_t copy, d2h;
+        bool on;
+        ~LeanScope() {
+            if (!on) return;
+            c->copy_stream = copy;
+            c->d2h_stream = d2h;
+            c->lean = false;
+        }
+    } lean_scope{c, c->copy_stream, c->d2h_stream, n_reads > 0 && n_bases <= lean_max_bases && n_bases <= c->chunk_bases};
+    if (lean_scope.on) {
+        c->copy_stream = c->stream;
+        c->d2h_stream = c->stream;
+        c->lean = true;
+    }
+    sl.lean = lean_scope.on;
     sl.params = *params;
     sl.counts = hits || total;
     sl.has_units = in.unit_id != nullptr;
@@ -1837,7 +1872,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
     if (total && !sl.total_direct) DCN_TRY(ensure_pinned(&sl.h_total, c->max_reads));
     const int off_pinned = is_pinned_host(in.offsets) ? 1 : 0, uid_pinned = is_pinned_host(in.unit_id) ? 1 : 0;
     static const bool no_off32 = getenv("DCN_NO_OFF32") != nullptr; // (A/B)
-    sl.off32 = n_reads > 0 && n_bases < (1ull << 32) && !no_off32;
+    sl.off32 = n_reads > 0 && n_bases < (1ull << 32) && !no_off32 && !sl.lean;
     if (sl.off32) DCN_TRY(ensure_pinned(&sl.h_off32, c->max_reads + 1));
     const int pk_pinned = in.packed ? ((is_pinned_host(in.packed) && is_pinned_host(in.invmask)) ? 1 : 0) : 0;
 
@@ -1998,7 +2033,7 @@ int submit_impl(dcn_ctx *c, const HostInput &in, const dcn_params *params, uint8
             }
             sl.chunks.push_back(ch);
             if ((rc = chunk_events(sl, sl.chunks.size())) != DCN_OK) break;
-            hipError_t he = hipEventRecord(sl.ev_h2d[sl.chunks.size() - 1], c->copy_stream);
+            hipError_t he = c->lean ? hipSuccess : hipEventRecord(sl.ev_h2d[sl.chunks.size() - 1], c->copy_stream);
             if (he != hipSuccess) {
                 rc = dcn_fail(DCN_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(he));
                 break;

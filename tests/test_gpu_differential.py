@@ -59,6 +59,8 @@ def random_case(rng, genome):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DCN_FUZZ_SEEDS", "12"))))  # more seeds for a soak run
 def test_differential(oracle, dcn, seed, monkeypatch):
+    if seed % 3 == 2:  # (a third of the seeds through the three-stream form of the host entry points: see test_gpu_host_pipeline.py)
+        monkeypatch.setenv("DCN_LEAN_MAX_BASES", "0")
     run_seed(oracle, dcn, seed, monkeypatch, 10)
 
 

@@ -13,6 +13,17 @@ from test_gpu_parity import make_index_pair, sample_reads
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["lean", "three-streams"])
+def submission_form(request, monkeypatch):
+    """every test of this file twice: batches of up to 16 Mbp that fit one chunk are submitted on ONE stream in their plain
+    form (64-bit offsets, whole mask words; api.hip submit_impl, `lean`), larger or chunked ones with copies, kernels and result
+    copies on three streams; DCN_LEAN_MAX_BASES=0 sends everything the second way, so that narrow offsets, the sparse mask and
+    the events between the streams are tested at test sizes too"""
+    if request.param == "three-streams":
+        monkeypatch.setenv("DCN_LEAN_MAX_BASES", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def genome():
     return random_reads(np.random.default_rng(101), 1, 150_000, 150_000)[0]

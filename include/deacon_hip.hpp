@@ -219,6 +219,61 @@ class FilterProcessor {
         check(dcn_filter_batch(ctx_, bases, offsets, unit_id, n_reads, &p, keep, hits, total));
     }
 
+    // ---- the shape of `impl ParallelProcessor for FilterProcessor` (local_filter.rs:345-405, pairs :482-573) ---------------
+    // paraseq calls process_record for every record of a record set (1,024 records by default) and then
+    // on_batch_complete; the record is only borrowed during the call.  A GPU call costs ~100 us whatever it carries
+    // (INTEGRATION.md 3.2), so this processor copies what it is handed, lets record sets GATHER, decides `flush_reads`
+    // of them in one call, and hands every record to the sink with its unit's decision, in input order -- where the
+    // reference formats kept records into its thread-local buffer and writes it under the lock (:365-367, :376-405).
+    struct Record {
+        std::string id, seq, qual;  // (qual empty: FASTA)
+    };
+    void set_flush_reads(std::size_t n) { flush_reads_ = n < 1 ? 1 : n; }  // default 1 << 16
+    void process_record(std::string_view id, std::string_view seq, std::string_view qual = {}) {  // :346-374
+        gathered_.push_back(Record{std::string(id), std::string(seq), std::string(qual)});
+        gathered_paired_ = false;
+    }
+    // :483-528 (two readers) and :409-448 (interleaved): mate 1 then mate 2 of one unit
+    void process_record_pair(std::string_view id1, std::string_view seq1, std::string_view qual1, std::string_view id2, std::string_view seq2,
+                             std::string_view qual2) {
+        gathered_.push_back(Record{std::string(id1), std::string(seq1), std::string(qual1)});
+        gathered_.push_back(Record{std::string(id2), std::string(seq2), std::string(qual2)});
+        gathered_paired_ = true;
+    }
+    // sink(const Record &, bool keep): every gathered record in input order (both mates of a pair get the pair's decision)
+    template <typename Sink>
+    void on_batch_complete(Sink &&sink) {  // :376-405 -- here: only once enough has gathered
+        if (gathered_.size() >= flush_reads_) flush(sink);
+    }
+    template <typename Sink>
+    void on_thread_complete(Sink &&sink) {  // what is left when the reader is done
+        flush(sink);
+    }
+    template <typename Sink>
+    void flush(Sink &&sink) {
+        if (gathered_.empty()) return;
+        // (max_batch_reads / max_batch_bases of the context bound a call: larger gatherings go in several)
+        std::size_t at = 0;
+        while (at < gathered_.size()) {
+            std::vector<std::string_view> views;
+            uint64_t bases = 0;
+            std::size_t end = at;
+            const std::size_t step = gathered_paired_ ? 2 : 1;
+            while (end < gathered_.size() && views.size() + step <= config_.max_batch_reads) {
+                uint64_t add = 0;
+                for (std::size_t j = 0; j < step; ++j) add += gathered_[end + j].seq.size();
+                if (!views.empty() && bases + add > config_.max_batch_bases) break;
+                for (std::size_t j = 0; j < step; ++j) views.emplace_back(gathered_[end + j].seq);
+                bases += add;
+                end += step;
+            }
+            const std::vector<bool> keep = keep_batch(views, gathered_paired_);
+            for (std::size_t i = at; i < end; ++i) sink(gathered_[i], bool(keep[(i - at) / step]));
+            at = end;
+        }
+        gathered_.clear();
+    }
+
     ProcessingStats stats() {
         std::array<uint64_t, DCN_N_STATS> c{};
         check(dcn_ctx_stats(ctx_, c.data()));
@@ -251,6 +306,9 @@ class FilterProcessor {
     std::vector<uint8_t> bases_, keep_;
     std::vector<uint64_t> offsets_;
     std::vector<uint32_t> unit_id_, hits_, total_;
+    std::vector<Record> gathered_;
+    bool gathered_paired_ = false;
+    std::size_t flush_reads_ = std::size_t(1) << 16;
 };
 
 // The reference's run() hands record batches to N worker threads that share one set, merges their output buffers

@@ -54,6 +54,29 @@ int main(int argc, char **argv) {
             for (bool b : only) std::printf(" %d", b ? 1 : 0);
             std::printf("\n");
         }
+        {   // the paraseq-shaped seam: record sets of 100 gather, 256 reads (or pairs' mates) decided per call, the rest at the end
+            deacon::FilterProcessor gp(index, cfg);
+            gp.set_flush_reads(256);
+            std::string line = "gathered";
+            std::size_t seen = 0, calls = 0;
+            auto sink = [&](const deacon::FilterProcessor::Record &r, bool keep) {
+                if (r.id != "r" + std::to_string(seen) || r.seq != reads[seen]) line += " OUT-OF-ORDER";
+                if (!paired || seen % 2 == 0 || seen + 1 == reads.size()) line += keep ? " 1" : " 0";
+                ++seen;
+            };
+            const std::size_t whole = paired ? reads.size() / 2 * 2 : reads.size();
+            for (std::size_t i = 0; i < whole; i += paired ? 2 : 1) {
+                if (paired) gp.process_record_pair("r" + std::to_string(i), reads[i], "", "r" + std::to_string(i + 1), reads[i + 1], "");
+                else gp.process_record("r" + std::to_string(i), reads[i]);
+                if ((i / (paired ? 2 : 1)) % 100 == 99) gp.on_batch_complete(sink), ++calls;
+            }
+            gp.on_thread_complete(sink);
+            if (paired && whole < reads.size()) {  // (a trailing single read is its own unit in filter_batch's reading of the list)
+                gp.process_record("r" + std::to_string(whole), reads[whole]);
+                gp.on_thread_complete(sink);
+            }
+            std::printf("%s\n", line.c_str());
+        }
         std::printf("stats %llu %llu %llu %llu %llu %llu\n", (unsigned long long)st.total_seqs,
                     (unsigned long long)st.filtered_seqs, (unsigned long long)st.total_bp,
                     (unsigned long long)st.output_bp, (unsigned long long)st.filtered_bp,

@@ -73,6 +73,8 @@ def test_cpp_layer_matches_oracle(driver, oracle, tmp_path, paired, deplete):
     ulen = np.bincount(uid, weights=lens).astype(np.int64) if paired else lens
     ucnt = np.bincount(uid) if paired else np.ones(len(reads), np.int64)
     assert [int(x) for x in next(l for l in lines if l.startswith("keeponly")).split()[1:]] == [int(x) for x in keep]
+    # process_record / on_batch_complete / on_thread_complete: record sets gather, 256 reads per call, input order kept
+    assert next(l for l in lines if l.startswith("gathered")).split()[1:] == [str(int(x)) for x in keep]
     st = [int(x) for x in next(l for l in lines if l.startswith("stats ")).split()[1:]]
     assert st == [len(reads), int(ucnt[~keep].sum()), int(lens.sum()), int(ulen[keep].sum()),
                   int(ulen[~keep].sum()), int(ucnt[keep].sum())]

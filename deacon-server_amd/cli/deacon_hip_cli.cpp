@@ -2664,6 +2664,115 @@ int run_filter(const FilterArgs &a_in) {
 }
 
 // ---- deacon index build (src/index.rs:167-308) / info (:539-560) ----------------------------------------------
+// A whole FASTA input as one batch, for `index build` (src/index.rs:167-308 reads the reference genome record by record the same
+// way its filter does): the record reader joins an 80-column genome's lines at ~1 GB/s on one thread, which was 40 % of an index
+// build.  Here the input is taken whole (mapped, or decompressed by the readers above), cut into slices at line starts, and every
+// slice's lines are classified (header / sequence) and copied on a thread of their own; a record's bases may come from several
+// slices.  false: not FASTA (the first record starts with '@') -- the caller falls back to the record reader.
+bool read_whole_fasta(const std::string &path, Batch &all, std::vector<char, DefaultInitAllocator<char>> &raw_store, MappedFile &mapped) {
+    const char *d = nullptr;
+    size_t n = 0;
+    if (mapped.open(path)) {
+        d = mapped.data;
+        n = mapped.size;
+    } else {
+        Input in(path);
+        // (a compressed genome is 3.5-4.5 x its file: room for 5 x at once, so that the text is not moved when the array grows;
+        // its pages are touched ahead of the reader by a thread of their own where the kernel offers that)
+        struct stat st;
+        size_t guess = 64u << 20;
+        if (::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode)) guess = std::max<size_t>(guess, (size_t)st.st_size * 5);
+        raw_store.resize(guess);
+        std::thread toucher;
+        std::atomic<bool> read_done{false};
+#ifdef MADV_POPULATE_WRITE
+        {
+            char *base = raw_store.data();
+            const size_t len = raw_store.size();
+            toucher = std::thread([base, len, &read_done] {
+                const uintptr_t lo = ((uintptr_t)base + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)base + len) & ~(uintptr_t)4095;
+                for (uintptr_t p = lo; p < hi && !read_done.load(); p += 64u << 20)
+                    (void)madvise((void *)p, std::min<size_t>(64u << 20, hi - p), MADV_POPULATE_WRITE);
+            });
+        }
+#endif
+        for (;;) {
+            if (n == raw_store.size()) {
+                read_done = true;
+                if (toucher.joinable()) toucher.join();
+                raw_store.resize(raw_store.size() + raw_store.size() / 2);
+            }
+            const size_t got = in.read(raw_store.data() + n, raw_store.size() - n);
+            if (got == 0) break;
+            n += got;
+        }
+        read_done = true;
+        if (toucher.joinable()) toucher.join();
+        d = raw_store.data();
+    }
+    size_t first = 0;
+    while (first < n && (d[first] == '\n' || d[first] == '\r')) ++first;
+    if (first == n) return true;  // empty input: no records
+    if (d[first] == '@') return false;
+    if (d[first] != '>') die("Invalid FASTX record start: expected '>' or '@'");
+    struct Slice {
+        size_t a = 0, b = 0, n_bases = 0, base0 = 0;
+        std::vector<std::pair<size_t, size_t>> headers;  // (start of the header line, bases of this slice in front of it)
+    };
+    const size_t n_slices = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(usable_cpus(), 32), n / (4u << 20)));
+    std::vector<Slice> sl(n_slices);
+    for (size_t t = 0; t < n_slices; ++t) {
+        size_t a = t == 0 ? first : n * t / n_slices;
+        if (t > 0) {  // forward to the next line start
+            const char *nl = (const char *)std::memchr(d + a, '\n', n - a);
+            a = nl ? (size_t)(nl - d) + 1 : n;
+        }
+        sl[t].a = a;
+        if (t > 0) sl[t - 1].b = a;
+    }
+    sl.back().b = n;
+    auto walk = [&](Slice &s, uint8_t *out) {  // out == nullptr: count only
+        size_t nb = 0;
+        for (size_t p = s.a; p < s.b;) {
+            const char *nl = (const char *)std::memchr(d + p, '\n', s.b - p);
+            size_t e = nl ? (size_t)(nl - d) : s.b, next = nl ? e + 1 : s.b;
+            if (e > p && d[e - 1] == '\r') --e;
+            if (e > p && d[p] == '>') {
+                if (!out) s.headers.emplace_back(p, nb);
+            } else {
+                if (out) std::memcpy(out + nb, d + p, e - p);
+                nb += e - p;
+            }
+            p = next;
+        }
+        s.n_bases = nb;
+    };
+    parallel_for(n_slices, n_slices, [&](size_t t) { walk(sl[t], nullptr); });
+    size_t total = 0;
+    for (auto &s : sl) s.base0 = total, total += s.n_bases;
+    all.bases.resize(total);
+    parallel_for(n_slices, n_slices, [&](size_t t) { walk(sl[t], all.bases.data() + sl[t].base0); });
+    all.ext = d;
+    all.offsets.clear();
+    all.recs.clear();
+    for (auto &s : sl)
+        for (auto &h : s.headers) {
+            Rec r;
+            size_t e = line_end(d, n, h.first);
+            if (e > h.first && d[e - 1] == '\r') --e;
+            r.id_off = h.first + 1;
+            r.id_len = (uint32_t)(e - h.first - 1);
+            r.seq_off = s.base0 + h.second;
+            r.qual_off = NO_QUAL;
+            r.seq_len = 0;
+            all.recs.push_back(r);
+            all.offsets.push_back(r.seq_off);
+        }
+    all.offsets.push_back(total);
+    for (size_t i = 0; i < all.recs.size(); ++i) all.recs[i].seq_len = (uint32_t)(all.offsets[i + 1] - all.offsets[i]);
+    return true;
+}
+
 int run_index_build(const std::string &input, unsigned k, unsigned w, const std::string &output, size_t capacity_millions,
                     float entropy, bool quiet) {
     auto start = std::chrono::steady_clock::now();
@@ -2671,19 +2780,33 @@ int run_index_build(const std::string &input, unsigned k, unsigned w, const std:
     if ((k + w - 1) % 2 == 0)
         die("Constraint violated: k + w - 1 must be odd (k=" + std::to_string(k) + ", w=" + std::to_string(w) + ")");
     std::fprintf(stderr, "Building index (k=%u, w=%u)\n", k, w);
-    FastxReader rd(input);
     Batch all;
-    while (rd.next(all)) {
-        if (!quiet) {
-            const Rec &r = all.recs.back();
-            std::fprintf(stderr, "  %.*s (%ubp)\n", (int)r.id_len, all.chars() + r.id_off, r.seq_len);
+    std::vector<char, DefaultInitAllocator<char>> raw_store;
+    MappedFile raw_map;
+    // a FASTA file (plain or compressed) is taken whole and its lines joined on all threads; stdin, FASTQ and
+    // DCN_CLI_NO_CHUNK_READER=1 go record by record
+    if (input != "-" && !std::getenv("DCN_CLI_NO_CHUNK_READER") && read_whole_fasta(input, all, raw_store, raw_map)) {
+        if (!quiet)
+            for (const Rec &r : all.recs) std::fprintf(stderr, "  %.*s (%ubp)\n", (int)r.id_len, all.chars() + r.id_off, r.seq_len);
+    } else {
+        all.reset();
+        FastxReader rd(input);
+        while (rd.next(all)) {
+            if (!quiet) {
+                const Rec &r = all.recs.back();
+                std::fprintf(stderr, "  %.*s (%ubp)\n", (int)r.id_len, all.chars() + r.id_off, r.seq_len);
+            }
         }
     }
+    const bool timing = std::getenv("DCN_CLI_TIMING") != nullptr;
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count(); };
+    const double t_read = since();
     dcn_index *raw = nullptr;
     // the capacity flag is only a pre-allocation hint (the table grows as needed); cap it by what the input can hold
     uint64_t hint = std::min<uint64_t>((uint64_t)capacity_millions * 1000000ull, all.bases.size() / 4 + 1024);
     deacon::check(dcn_index_build(all.bases.data(), all.offsets.data(), (uint32_t)all.recs.size(), (uint8_t)k, (uint8_t)w,
                                   entropy, hint, 0, &raw));
+    const double t_built = since();
     uint64_t n = 0;
     deacon::check(dcn_index_header(raw, nullptr, nullptr, &n));
     std::fprintf(stderr, "Indexed %llu minimizers from %zu sequence(s) (%zubp)\n", (unsigned long long)n, all.recs.size(),
@@ -2693,6 +2816,9 @@ int run_index_build(const std::string &input, unsigned k, unsigned w, const std:
     int rc = dcn_index_write_file(raw, path.c_str());
     dcn_index_destroy(raw);
     deacon::check(rc);
+    if (timing)
+        std::fprintf(stderr, "timing: input read %.3f s, index built on the GPU %.3f s, index file written %.3f s\n", t_read, t_built - t_read,
+                     since() - t_built);
     std::fprintf(stderr, "Completed in %s\n",
                  fmt_duration(std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count()).c_str());
     return 0;

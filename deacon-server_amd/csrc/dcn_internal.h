@@ -22,6 +22,9 @@ int dcn_fail(int code, const std::string &msg);
                             std::string(#expr) + ": " + hipGetErrorString(_e));                    \
     } while (0)
 
+// memcpy on the host pool's threads (api.hip): large copies into memory nobody has touched yet are first-touch bound on one thread
+void dcn_host_parallel_copy(void *dst, const void *src, size_t n);
+
 // ----------------------------------------------------------------------------------------------------
 // device-resident index: open-addressing set over groups of DCN_GROUP_SLOTS u64 slots, linear probing group by
 // group.  Slot value 0 = empty; key 0 is tracked by `has_zero`.

@@ -7,6 +7,8 @@
 // varint: b < 251 -> the value; 0xFB + u16 LE; 0xFC + u32 LE; 0xFD + u64 LE.
 // Loading mirrors load_minimizer_hashes (src/index.rs:80-107) minus the host hash set: the keys go straight
 // to the device table builder, which merges duplicates.
+#include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
@@ -14,6 +16,10 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "dcn_internal.h"
 
@@ -163,15 +169,81 @@ void encode_block(const uint64_t *keys, size_t n, unsigned threads, std::vector<
 } // namespace
 
 int dcn_write_index_file(const char *path, uint8_t k, uint8_t w, const uint64_t *keys, uint64_t n) {
-    FILE *f = fopen(path, "wb");
-    if (!f) return dcn_fail(DCN_ERR_IO, std::string("Failed to create output file ") + path);
-    setvbuf(f, nullptr, _IONBF, 0); // blocks are tens of megabytes: no second copy through stdio
-    uint8_t head[3 + 9] = {2, k, w};
-    size_t head_len = (size_t)(put_varint(head + 3, n) - head);
-    int rc = fwrite(head, 1, head_len, f) == head_len ? DCN_OK : dcn_fail(DCN_ERR_IO, "short write");
     unsigned hw = std::thread::hardware_concurrency();
     unsigned threads = std::min(8u, hw ? hw : 1u);
     if (const char *e = getenv("DCN_HOST_THREADS")) threads = (unsigned)std::max(1, atoi(e));
+    uint8_t head[3 + 9] = {2, k, w};
+    const size_t head_len = (size_t)(put_varint(head + 3, n) - head);
+    // A regular file is written by all threads at once: the size of every slice's encoding is known after one pass over the
+    // keys, so each thread encodes its slice block by block and writes it at its own offset (one writer behind one encoder
+    // moved 1 GB/s into tmpfs -- 0.45 s of a 1.05 s index build of a 400 Mbp genome; the page cache takes several writers).
+    // Anything else (a pipe, /dev/stdout) takes the blocks in order from one writer, as before.
+    int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return dcn_fail(DCN_ERR_IO, std::string("Failed to create output file ") + path);
+    struct stat st;
+    const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !getenv("DCN_INDEX_WRITE_SERIAL");
+    if (regular && n > 0) {
+        threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads, n / 65536 + 1));
+        std::vector<uint64_t> part(threads + 1, 0);
+        auto slice = [&](unsigned t, uint64_t &lo, uint64_t &hi) {
+            lo = n * t / threads;
+            hi = n * (t + 1) / threads;
+        };
+        auto run = [&](auto &&fn) {
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < threads; ++t) pool.emplace_back(fn, t);
+            fn(0u);
+            for (auto &th : pool) th.join();
+        };
+        run([&](unsigned t) {
+            uint64_t lo, hi, bytes = 0;
+            slice(t, lo, hi);
+            for (uint64_t i = lo; i < hi; ++i) bytes += varint_size(keys[i]);
+            part[t + 1] = bytes;
+        });
+        part[0] = head_len;
+        for (unsigned t = 0; t < threads; ++t) part[t + 1] += part[t];
+        std::atomic<bool> failed{false};
+        auto write_all = [&](const uint8_t *p, size_t len, uint64_t off) {
+            while (len) {
+                const ssize_t w_ = ::pwrite(fd, p, len, (off_t)off);
+                if (w_ < 0) {
+                    if (errno == EINTR) continue;
+                    failed = true;
+                    return;
+                }
+                p += w_;
+                len -= (size_t)w_;
+                off += (uint64_t)w_;
+            }
+        };
+        write_all(head, head_len, 0);
+        run([&](unsigned t) {
+            uint64_t lo, hi;
+            slice(t, lo, hi);
+            std::vector<uint8_t> buf;
+            uint64_t off = part[t];
+            const uint64_t STEP = 1u << 20;  // keys per block
+            for (uint64_t i = lo; i < hi && !failed; i += STEP) {
+                const uint64_t m = std::min<uint64_t>(STEP, hi - i);
+                buf.resize(m * 9);
+                uint8_t *q = buf.data();
+                for (uint64_t j = 0; j < m; ++j) q = put_varint(q, keys[i + j]);
+                write_all(buf.data(), (size_t)(q - buf.data()), off);
+                off += (uint64_t)(q - buf.data());
+            }
+        });
+        int rc = failed ? dcn_fail(DCN_ERR_IO, "short write") : DCN_OK;
+        if (::close(fd) != 0 && rc == DCN_OK) rc = dcn_fail(DCN_ERR_IO, "close failed");
+        return rc;
+    }
+    FILE *f = fdopen(fd, "wb");
+    if (!f) {
+        ::close(fd);
+        return dcn_fail(DCN_ERR_IO, std::string("Failed to create output file ") + path);
+    }
+    setvbuf(f, nullptr, _IONBF, 0); // blocks are tens of megabytes: no second copy through stdio
+    int rc = fwrite(head, 1, head_len, f) == head_len ? DCN_OK : dcn_fail(DCN_ERR_IO, "short write");
     const uint64_t BLOCK = 8ull << 20;
     std::vector<uint8_t> buf[2];
     std::thread writer;

@@ -393,20 +393,34 @@ __global__ void count_valid_kernel(const uint8_t *valid, uint64_t n, unsigned lo
 
 __global__ void export_keys_kernel(const uint64_t *slots, uint64_t n_slots, uint64_t *out, uint64_t capacity,
                                    unsigned long long *cursor) {
-    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // A wave takes SPAN x 64 consecutive slots at a time and asks the cursor ONCE for all the keys in them: the table is
+    // sparse (8-40 slots per key) and large, and one atomic per 64 slots on one address was the whole kernel (a 34 GB table:
+    // 67 M of them, 0.2 s; the slots themselves stream by in 10 ms).
+    constexpr int SPAN = 16;
     const int lane = threadIdx.x & 63;
-    // whole waves iterate together: one cursor atomic per wave and iteration
-    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < n_slots; i0 += stride) {
-        uint64_t i = i0 + lane;
-        uint64_t key = i < n_slots ? slots[i] : 0;
-        unsigned long long m = __ballot(key != 0);
-        if (m == 0) continue;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t w0 = wave * (64ull * SPAN); w0 < n_slots; w0 += n_waves * (64ull * SPAN)) {
+        uint64_t key[SPAN];
+        unsigned long long m[SPAN];
+        unsigned total = 0;
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j) {
+            const uint64_t i = w0 + 64ull * j + lane;
+            key[j] = i < n_slots ? slots[i] : 0;
+            m[j] = __ballot(key[j] != 0);
+            total += (unsigned)__popcll(m[j]);
+        }
+        if (total == 0) continue;
         unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)total);
         base = __shfl(base, 0, 64);
-        if (key) {
-            unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1));
-            if (at < capacity) out[at] = key;
+#pragma unroll
+        for (int j = 0; j < SPAN; ++j) {
+            if (key[j]) {
+                const unsigned long long at = base + (unsigned long long)__popcll(m[j] & ((1ull << lane) - 1));
+                if (at < capacity) out[at] = key[j];
+            }
+            base += (unsigned long long)__popcll(m[j]);
         }
     }
 }
@@ -558,7 +572,46 @@ int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity
         uint64_t n_slots = idx->n_groups * DCN_GROUP_SLOTS;
         uint32_t blocks = (uint32_t)std::min<uint64_t>((n_slots + 255) / 256, 256 * 16);
         hipLaunchKernelGGL(export_keys_kernel, dim3(blocks), dim3(256), 0, 0, idx->d_slots, n_slots, d_out, n_nonzero, d_cur);
-        e = hipMemcpy(host_out + at, d_out, n_nonzero * sizeof(uint64_t), hipMemcpyDeviceToHost);
+        // One hipMemcpy into the caller's pageable (and usually untouched) array moved 2 GB/s: the runtime stages it on one
+        // thread, first-touch faults included -- 0.2 s of a 0.7 s index build for 50 M keys, seconds for a panhuman-sized
+        // union.  Pieces of 32 MB through two page-locked buffers instead, each copied out by the host threads while the next
+        // one crosses the link.
+        const uint64_t bytes = n_nonzero * sizeof(uint64_t), PIECE = 32ull << 20;
+        void *pin[2] = {nullptr, nullptr};
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool piped = bytes > PIECE && hipHostMalloc(&pin[0], PIECE, hipHostMallocDefault) == hipSuccess &&
+                     hipHostMalloc(&pin[1], PIECE, hipHostMallocDefault) == hipSuccess &&
+                     hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+        if (piped) {
+            e = hipDeviceSynchronize();  // (the export kernel ran on the null stream)
+            const uint64_t n_pieces = (bytes + PIECE - 1) / PIECE;
+            auto issue = [&](uint64_t i) {
+                const uint64_t off = i * PIECE, len = std::min(PIECE, bytes - off);
+                hipError_t r = hipMemcpyAsync(pin[i & 1], (const uint8_t *)d_out + off, len, hipMemcpyDeviceToHost, st);
+                return r == hipSuccess ? hipEventRecord(ev[i & 1], st) : r;
+            };
+            if (e == hipSuccess) e = issue(0);
+            for (uint64_t i = 0; i < n_pieces && e == hipSuccess; ++i) {
+                e = hipEventSynchronize(ev[i & 1]);
+                if (e != hipSuccess) break;
+                const uint64_t off = i * PIECE, len = std::min(PIECE, bytes - off);
+                // (piece i + 1 goes into the other buffer, which piece i - 1 has left)
+                if (i + 1 < n_pieces) e = issue(i + 1);
+                dcn_host_parallel_copy((uint8_t *)(host_out + at) + off, pin[i & 1], len);
+            }
+            if (e != hipSuccess) (void)hipStreamSynchronize(st);
+        } else {
+            (void)hipGetLastError();
+            e = hipMemcpy(host_out + at, d_out, bytes, hipMemcpyDeviceToHost);
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (ev[i]) hipEventDestroy(ev[i]);
+            if (pin[i]) hipHostFree(pin[i]);
+        }
+        if (st) hipStreamDestroy(st);
     }
     hipFree(d_out);
     if (d_cur) hipFree(d_cur);

@@ -13,7 +13,9 @@ def test_index_file_codec(tmp_path):
                            "-Wno-unused-value", "-I", csrc, "-I", os.path.join(ROOT, "include"),
                            os.path.join(csrc, "index_file.cpp"), os.path.join(ROOT, "tests", "cpp", "index_file_test.cpp"),
                            "-o", str(exe), "-lpthread"])
-    for threads in ("1", "3", "8"):
-        out = subprocess.run([str(exe), str(tmp_path / "t.idx")], capture_output=True, env=dict(os.environ, DCN_HOST_THREADS=threads))
+    # (a regular file is written by all threads at their own offsets; DCN_INDEX_WRITE_SERIAL=1 is the one-writer form that
+    # pipes and /dev/stdout take)
+    for threads, extra in (("1", {}), ("3", {}), ("8", {}), ("3", {"DCN_INDEX_WRITE_SERIAL": "1"})):
+        out = subprocess.run([str(exe), str(tmp_path / "t.idx")], capture_output=True, env=dict(os.environ, DCN_HOST_THREADS=threads, **extra))
         assert out.returncode == 0, out.stderr.decode()
         assert b"index file codec ok" in out.stdout

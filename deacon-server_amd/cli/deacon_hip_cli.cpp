@@ -2920,6 +2920,84 @@ void usage() {
                  "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n");
 }
 
+// `deacon-hip <subcommand> --help`: the options of src/main.rs:17-235 with the reference's short / long names and defaults,
+// plus the two this tool adds (--gpus, --devices).  Printed to stdout with exit code 0, as clap does.
+bool subcommand_help(const std::vector<std::string> &args) {
+    bool asked = false;
+    for (size_t i = 1; i < args.size(); ++i) asked |= args[i] == "--help" || args[i] == "-h";
+    if (!asked) return false;
+    const std::string sub = args[0] == "index" && args.size() >= 2 && args[1][0] != '-' ? "index " + args[1] : args[0];
+    const char *text = nullptr;
+    if (sub == "filter")
+        text = "Keep or discard DNA fastx records with sufficient minimizer hits to an index\n\n"
+               "Usage: deacon-hip filter [OPTIONS] <INDEX> [INPUT] [INPUT2]\n\n"
+               "Arguments:\n"
+               "  <INDEX>   Path to minimizer index file\n"
+               "  [INPUT]   Optional path to fastx file (or - for stdin; gz, bgzf, zst, xz and bz2 found by content) [default: -]\n"
+               "  [INPUT2]  Optional path to second paired fastx file (or - for interleaved stdin)\n\n"
+               "Options:\n"
+               "  -o, --output <OUTPUT>          Path to output fastx file (or - for stdout; .gz, .zst and .xz by extension) [default: -]\n"
+               "  -O, --output2 <OUTPUT2>        Optional path to second paired output fastx file\n"
+               "  -a, --abs-threshold <N>        Minimum absolute number of minimizer hits for a match [default: 2]\n"
+               "  -r, --rel-threshold <F>        Minimum relative proportion (0.0-1.0) of minimizer hits for a match [default: 0.01]\n"
+               "  -p, --prefix-length <N>        Search only the first N nucleotides per sequence (0 = entire sequence) [default: 0]\n"
+               "  -d, --deplete                  Discard matching sequences (invert filtering behaviour)\n"
+               "  -R, --rename                   Replace sequence headers with incrementing numbers\n"
+               "  -s, --summary <SUMMARY>        Path to JSON summary output file\n"
+               "  -t, --threads <THREADS>        Number of host threads (0 = auto) [default: 3/4 of the usable CPUs, at least 8]\n"
+               "      --compression-level <N>    Output compression level (1-9 for gz & xz; 1-22 for zstd) [default: 2]\n"
+               "      --debug                    Output sequences with minimizer hits to stderr\n"
+               "  -q, --quiet                    Suppress progress reporting\n"
+               "      --gpus <N>                 Use GPUs 0..N-1, one pipeline context and one index replica each [default: 1]\n"
+               "      --devices <LIST>           Explicit device list, e.g. 0,2,3 (a repeated id = another context on that GPU)\n"
+               "  -h, --help                     Print help\n";
+    else if (sub == "index build")
+        text = "Index minimizers contained within a fastx file\n\n"
+               "Usage: deacon-hip index build [OPTIONS] <INPUT>\n\n"
+               "Arguments:\n  <INPUT>  Path to input fastx file (gz, bgzf, zst, xz and bz2 found by content)\n\n"
+               "Options:\n"
+               "  -k <K>                         K-mer length used for indexing (1-57) [default: 31]\n"
+               "  -w <W>                         Minimizer window size used for indexing [default: 15]\n"
+               "  -o, --output <OUTPUT>          Path to output file (- for stdout) [default: -]\n"
+               "  -c, --capacity <CAPACITY>      Preallocated index capacity in millions of minimizers (accepted; the device table sizes itself) [default: 400]\n"
+               "  -t, --threads <THREADS>        Accepted for compatibility (the scan runs on the GPU)\n"
+               "  -q, --quiet                    Suppress sequence header output\n"
+               "  -e, --entropy-threshold <F>    Minimum scaled entropy threshold for k-mer filtering (0.0-1.0) [default: 0.0]\n"
+               "  -h, --help                     Print help\n";
+    else if (sub == "index info")
+        text = "Show index information\n\nUsage: deacon-hip index info <INDEX>\n\nArguments:\n  <INDEX>  Path to index file\n";
+    else if (sub == "index union")
+        text = "Combine multiple minimizer indexes (A u B...)\n\n"
+               "Usage: deacon-hip index union [OPTIONS] <INPUTS>...\n\n"
+               "Arguments:\n  <INPUTS>...  Path(s) to one or more index file(s)\n\n"
+               "Options:\n"
+               "  -o, --output <OUTPUT>      Path to output file (- for stdout) [default: -]\n"
+               "  -c, --capacity <CAPACITY>  Accepted for compatibility (the device table sizes itself)\n"
+               "  -h, --help                 Print help\n";
+    else if (sub == "index diff")
+        text = "Subtract minimizers in one index from another (A - B)\n\n"
+               "Usage: deacon-hip index diff [OPTIONS] <FIRST> <SECOND>\n\n"
+               "Arguments:\n"
+               "  <FIRST>   Path to first index file\n"
+               "  <SECOND>  Path to second index file or FASTX file (or - for stdin when using FASTX)\n\n"
+               "Options:\n"
+               "  -k, --kmer-length <K>    K-mer length (required if second argument is FASTX file, 1-32)\n"
+               "  -w, --window-size <W>    Window size (required if second argument is FASTX file)\n"
+               "  -o, --output <OUTPUT>    Path to output file (- for stdout) [default: -]\n"
+               "  -h, --help               Print help\n";
+    else if (sub == "index")
+        text = "Build and compose minimizer indexes\n\n"
+               "Usage: deacon-hip index <COMMAND>\n\n"
+               "Commands:\n"
+               "  build  Index minimizers contained within a fastx file\n"
+               "  info   Show index information\n"
+               "  union  Combine multiple minimizer indexes (A u B...)\n"
+               "  diff   Subtract minimizers in one index from another (A - B)\n";
+    if (!text) return false;
+    std::fputs(text, stdout);
+    return true;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -2937,6 +3015,7 @@ int main(int argc, char **argv) {
             usage();
             return 0;
         }
+        if (subcommand_help(args)) return 0;
         auto need = [&](size_t i) -> const std::string & {
             if (i >= args.size()) die("missing value for " + args[i - 1]);
             return args[i];

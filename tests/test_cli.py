@@ -57,6 +57,26 @@ def test_binary_exists_version_and_usage():  # tests/cli_tests.rs
     assert p.returncode == 2 and b"Usage" in p.stderr
 
 
+def test_every_subcommand_prints_its_options():  # src/main.rs:17-235 (clap: help on stdout, exit code 0)
+    wanted = {
+        ("filter",): [b"<INDEX>", b"--output2", b"--abs-threshold", b"--rel-threshold", b"--prefix-length", b"--deplete",
+                      b"--rename", b"--summary", b"--threads", b"--compression-level", b"--debug", b"--quiet", b"--gpus"],
+        ("index",): [b"build", b"info", b"union", b"diff"],
+        ("index", "build"): [b"-k <K>", b"-w <W>", b"--output", b"--capacity", b"--entropy-threshold", b"[default: 31]"],
+        ("index", "info"): [b"<INDEX>"],
+        ("index", "union"): [b"<INPUTS>...", b"--output"],
+        ("index", "diff"): [b"<FIRST>", b"<SECOND>", b"--kmer-length", b"--window-size"],
+    }
+    for sub, words in wanted.items():
+        for flag in ("--help", "-h"):
+            p = run(*sub, flag)
+            assert p.stdout.startswith(b"Usage") or b"\n\nUsage: deacon-hip " + " ".join(sub).encode() in p.stdout, sub
+            for word in words:
+                assert word in p.stdout, (sub, word)
+    # the flag is found behind other arguments too, before anything is opened
+    assert b"Usage: deacon-hip filter" in run("filter", "no-such.idx", "-d", "--help").stdout
+
+
 def test_filter_fails_loudly_without_gpu(tmp_path, dcn):
     import ctypes
     n = ctypes.c_int()

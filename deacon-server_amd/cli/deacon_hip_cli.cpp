@@ -17,7 +17,9 @@
 // The server/client commands live in deacon-server_amd/server.py / client.py.
 // Input/output compression: gzip via zlib; zstd and xz through the installed runtime libraries (codecs.hpp).
 #include <fcntl.h>
+#include <spawn.h>
 #include <sys/mman.h>
+#include <sys/wait.h>
 #include <sched.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -2916,8 +2918,37 @@ int run_index_diff(const std::string &first, const std::string &second, int k_op
 void usage() {
     std::fprintf(stderr,
                  "Usage: deacon-hip <COMMAND>\n\nCommands:\n  index   Build and compose minimizer indexes (build, info, union, diff)\n"
-                 "  filter  Keep or discard DNA fastx records with sufficient minimizer hits to an index\n\n"
+                 "  filter  Keep or discard DNA fastx records with sufficient minimizer hits to an index\n"
+                 "  server  Hold a pre-loaded minimizer index on the GPU for filtering with the client command\n"
+                 "  client  Alternate version of filter: minimizers computed here, the index held by a server\n\n"
                  "Options:\n  -h, --help     Print help\n  -V, --version  Print version\n");
+}
+
+// `deacon-hip server IDX -p PORT` and `deacon-hip client ADDR [INPUT] [INPUT2] ...` (src/main.rs:86-157): the server surface is
+// the package's Python (deacon_server_amd/server.py, client.py over the same library); the tool starts it as a CHILD process
+// with the repository root on PYTHONPATH and returns its exit code (never an exec of this process: it is linked against the
+// HIP runtime).
+int run_python_module(const std::vector<std::string> &args) {
+    char self[4096];
+    const ssize_t n = ::readlink("/proc/self/exe", self, sizeof self - 1);
+    if (n <= 0) die("cannot find the tool's own path");
+    self[n] = 0;
+    std::string root(self);  // <root>/deacon-server_amd/bin/deacon-hip
+    for (int up = 0; up < 3; ++up) root.erase(root.find_last_of('/'));
+    std::string pp = root;
+    if (const char *e = std::getenv("PYTHONPATH")) pp += std::string(":") + e;
+    ::setenv("PYTHONPATH", pp.c_str(), 1);
+    const std::string module = "deacon_server_amd." + args[0];
+    std::vector<std::string> owned = {"python3", "-m", module};
+    owned.insert(owned.end(), args.begin() + 1, args.end());
+    std::vector<char *> argv;
+    for (auto &a : owned) argv.push_back(a.data());
+    argv.push_back(nullptr);
+    pid_t pid = 0;
+    if (::posix_spawnp(&pid, "python3", nullptr, nullptr, argv.data(), environ) != 0) die("cannot start python3");
+    int status = 0;
+    while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+    return WIFEXITED(status) ? WEXITSTATUS(status) : 128 + WTERMSIG(status);
 }
 
 // `deacon-hip <subcommand> --help`: the options of src/main.rs:17-235 with the reference's short / long names and defaults,
@@ -3015,6 +3046,7 @@ int main(int argc, char **argv) {
             usage();
             return 0;
         }
+        if (args[0] == "server" || args[0] == "client") return run_python_module(args);
         if (subcommand_help(args)) return 0;
         auto need = [&](size_t i) -> const std::string & {
             if (i >= args.size()) die("missing value for " + args[i - 1]);

@@ -73,6 +73,11 @@ def test_every_subcommand_prints_its_options():  # src/main.rs:17-235 (clap: hel
             assert p.stdout.startswith(b"Usage") or b"\n\nUsage: deacon-hip " + " ".join(sub).encode() in p.stdout, sub
             for word in words:
                 assert word in p.stdout, (sub, word)
+    # server / client (src/main.rs:86-157) are the package's Python, started by the tool as a child process
+    p = run("client", "--help")
+    assert b"usage: deacon-hip client" in p.stdout and b"--output2" in p.stdout and b"server_address" in p.stdout
+    p = run("server", check=False)
+    assert p.returncode == 2 and b"deacon-hip server" in p.stderr
     # the flag is found behind other arguments too, before anything is opened
     assert b"Usage: deacon-hip filter" in run("filter", "no-such.idx", "-d", "--help").stdout
 

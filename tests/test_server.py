@@ -218,3 +218,167 @@ def test_gpu_server_debug_kmers(gpu_server, oracle):
     assert got == want
     assert sum(len(g[3]) for g in got) > 100
     rf.close()
+
+
+# ---- the client as a command (src/main.rs:97-157, remote_filter::run): file to file through the server -------------------
+
+def _oracle_remote_filter(CL, O, url, abs_threshold=2, rel_threshold=0.01, prefix_length=0, deplete=False, debug=False):
+    """A RemoteFilter whose minimizers come from the oracle instead of the GPU: the CPU tests' stand-in for the device
+    (the product's RemoteFilter has no such path)."""
+    class OracleRemoteFilter(CL.RemoteFilter):
+        def __init__(self):
+            self.server_address = url
+            header = CL.get_server_index_header(url)
+            self.kmer_length, self.window_size = int(header["kmer_length"]), int(header["window_size"])
+            self.abs_threshold, self.rel_threshold = abs_threshold, rel_threshold
+            self.prefix_length, self.deplete, self.debug = prefix_length, deplete, debug
+
+        def minimizers(self, reads):
+            off, hs, ps = [0], [], []
+            for r in reads:
+                h, p = O.minimizer_hashes_and_positions(r, self.kmer_length, self.window_size, self.prefix_length)
+                hs.append(np.asarray(h, np.uint64))
+                ps.append(np.asarray(p, np.uint32))
+                off.append(off[-1] + len(h))
+            return (np.asarray(off, np.uint64), np.concatenate(hs) if hs else np.zeros(0, np.uint64),
+                    np.concatenate(ps) if ps else np.zeros(0, np.uint32))
+
+        def close(self):
+            pass
+    return OracleRemoteFilter()
+
+
+def _fastq_bytes(recs):
+    return b"".join(b"@" + i + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in recs)
+
+
+def _named(reads):
+    return [(f"read{i} desc {i}".encode(), r) for i, r in enumerate(reads) if r]
+
+
+def test_read_fastx_shapes():
+    import io
+    from deacon_server_amd import client as CL
+    fa = b"\n>a one\nACGT\nAC\n\n>b\n>c\nGG\r\n"
+    assert list(CL.read_fastx(io.BytesIO(fa))) == [(b"a one", b"ACGTAC", None), (b"b", b"", None), (b"c", b"GG", None)]
+    fq = b"@q1 x\nACGT\n+\nIIII\n\n@q2\nAC\nGT\n+q2\nII\nII\n@q3\n\n+\n\n"
+    assert list(CL.read_fastx(io.BytesIO(fq))) == [(b"q1 x", b"ACGT", b"IIII"), (b"q2", b"ACGT", b"IIII"), (b"q3", b"", b"")]
+    with pytest.raises(CL.ClientError):
+        list(CL.read_fastx(io.BytesIO(b"@q\nACGT\n+\nII\n")))
+    with pytest.raises(CL.ClientError):
+        list(CL.read_fastx(io.BytesIO(b"@q\nACGT\n")))
+    with pytest.raises(CL.ClientError):
+        list(CL.read_fastx(io.BytesIO(b"ACGT\n")))
+    assert list(CL.read_fastx(io.BytesIO(b""))) == []
+
+
+@pytest.mark.parametrize("deplete,rename,gz", [(False, False, False), (True, True, False), (False, True, True)])
+def test_client_command_single_over_http(oracle_server, oracle, tmp_path, deplete, rename, gz):
+    import gzip
+    import io
+    from deacon_server_amd import client as CL
+    srv, url, index, reads, path = oracle_server
+    recs = _named(reads)
+    inp = tmp_path / ("in.fastq.gz" if gz else "in.fastq")
+    inp.write_bytes(gzip.compress(_fastq_bytes(recs)) if gz else _fastq_bytes(recs))
+    out = tmp_path / ("out.fastq.gz" if gz else "out.fastq")
+    log = io.StringIO()
+    summary = CL.run_client(url, str(inp), None, str(out), None, 2, 0.01, 0, deplete, rename, str(tmp_path / "s.json"),
+                            remote_filter=_oracle_remote_filter(CL, oracle, url, deplete=deplete), log=log)
+    bases, offsets = oracle.concat_reads([s for _, s in recs])
+    keep, hits, total = oracle.filter_batch(index, bases, offsets, None, 2, 0.01, 0, deplete)
+    kept = [(i, s) for (i, s), k in zip(recs, keep) if k]
+    assert 0 < len(kept) < len(recs)
+    want = _fastq_bytes([(str(n + 1).encode(), s) if rename else (i, s) for n, (i, s) in enumerate(kept)])
+    got = out.read_bytes()
+    assert (gzip.decompress(got) if gz else got) == want
+    assert summary == {**json.loads((tmp_path / "s.json").read_text())}
+    assert (summary["seqs_in"], summary["seqs_out"], summary["seqs_removed"]) == (len(recs), len(kept), len(recs) - len(kept))
+    assert summary["bp_in"] == sum(len(s) for _, s in recs) and summary["bp_out"] == sum(len(s) for _, s in kept)
+    assert summary["bp_removed"] == summary["bp_in"] - summary["bp_out"]
+    assert (summary["k"], summary["w"], summary["deplete"], summary["rename"]) == (K, W, deplete, rename)
+    assert summary["index"] == CL.get_server_index_version(url) and summary["input2"] is None
+    text = log.getvalue()
+    assert text.startswith(f"Deacon v{CL.VERSION}; mode: {'deplete' if deplete else 'search'}; input: single; options: "
+                           f"abs_threshold=2, rel_threshold=0.01{', rename' if rename else ''}, threads=8\n")
+    assert f"Loaded index (k={K}, w={W}) in " in text and f"Retained {len(kept)}/{len(recs)} sequences (" in text
+    assert "Completed in " in text and "Summary saved to " in text
+
+
+def test_client_command_pairs_over_http(oracle_server, oracle, tmp_path, monkeypatch):
+    import io
+    import types
+    from deacon_server_amd import client as CL
+    srv, url, index, reads, path = oracle_server
+    recs = _named(reads)
+    recs = recs[:len(recs) // 2 * 2]
+    r1, r2 = recs[0::2], recs[1::2]
+    (tmp_path / "r1.fq").write_bytes(_fastq_bytes(r1))
+    (tmp_path / "r2.fa").write_bytes(b"".join(b">" + i + b"\n" + s[:50] + b"\n" + s[50:] + b"\n" for i, s in r2))  # FASTA mates, two lines
+    bases, offsets = oracle.concat_reads([s for _, s in recs])
+    unit_id = (np.arange(len(recs)) // 2).astype(np.uint32)
+    keep, hits, total = oracle.filter_batch(index, bases, offsets, unit_id, 2, 0.01, 0, False)
+    assert 0 < int(keep.sum()) < len(keep)
+    want1 = _fastq_bytes([p for p, k in zip(r1, keep) if k])
+    want2 = b"".join(b">" + i + b"\n" + s + b"\n" for (i, s), k in zip(r2, keep) if k)
+    log = io.StringIO()
+    # two files in, two files out
+    s = CL.run_client(url, str(tmp_path / "r1.fq"), str(tmp_path / "r2.fa"), str(tmp_path / "o1.fq"), str(tmp_path / "o2.fa"),
+                      debug=True, remote_filter=_oracle_remote_filter(CL, oracle, url, debug=True), log=log)
+    assert (tmp_path / "o1.fq").read_bytes() == want1 and (tmp_path / "o2.fa").read_bytes() == want2
+    assert s["seqs_in"] == len(recs) and s["seqs_out"] == 2 * int(keep.sum()) and s["input2"] == str(tmp_path / "r2.fa")
+    debug_lines = [ln for ln in log.getvalue().splitlines() if ln.startswith("DEBUG: ")]
+    assert len(debug_lines) == int((hits > 0).sum())  # pairs are only reported when something hit (remote_filter.rs:1000)
+    first = int(np.flatnonzero(hits > 0)[0])
+    assert debug_lines[0] == (f"DEBUG: {r1[first][0].decode()}/{r2[first][0].decode()} hits={hits[first]}/{total[first]} "
+                              f"keep={'true' if keep[first] else 'false'} kmers=[]")
+    # two files in, one file out: mates interleaved, renamed in output order
+    CL.run_client(url, str(tmp_path / "r1.fq"), str(tmp_path / "r2.fa"), str(tmp_path / "both.fx"), None, rename=True,
+                  remote_filter=_oracle_remote_filter(CL, oracle, url), log=io.StringIO())
+    n, want = 0, b""
+    for a, b, k in zip(r1, r2, keep):
+        if k:
+            want += _fastq_bytes([(str(n + 1).encode(), a[1])]) + b">" + str(n + 2).encode() + b"\n" + b[1] + b"\n"
+            n += 2
+    assert (tmp_path / "both.fx").read_bytes() == want
+    # interleaved stdin; an odd record count is an error that names the count
+    inter = _fastq_bytes([x for pair in zip(r1, r2) for x in pair])
+    monkeypatch.setattr(CL.sys, "stdin", types.SimpleNamespace(buffer=io.BytesIO(inter)))
+    CL.run_client(url, "-", "-", str(tmp_path / "i.fq"), None, remote_filter=_oracle_remote_filter(CL, oracle, url), log=io.StringIO())
+    assert (tmp_path / "i.fq").read_bytes() == _fastq_bytes([x for a, b, k in zip(r1, r2, keep) if k for x in (a, b)])
+    monkeypatch.setattr(CL.sys, "stdin", types.SimpleNamespace(buffer=io.BytesIO(_fastq_bytes(recs[:3]))))
+    with pytest.raises(CL.ClientError, match="Uneven number of interleaved sequence pairs. Found 3 records."):
+        CL.run_client(url, "-", "-", str(tmp_path / "j.fq"), None, remote_filter=_oracle_remote_filter(CL, oracle, url), log=io.StringIO())
+
+
+def test_client_command_prefix_is_a_u8_like_the_reference(oracle_server, oracle, tmp_path):
+    import io
+    from deacon_server_amd import client as CL
+    srv, url, index, reads, path = oracle_server
+    recs = _named(reads)
+    (tmp_path / "in.fq").write_bytes(_fastq_bytes(recs))
+    log = io.StringIO()
+    s = CL.run_client(url, str(tmp_path / "in.fq"), None, str(tmp_path / "o.fq"), None, 1, 0.0, 256 + 60,
+                      remote_filter=_oracle_remote_filter(CL, oracle, url, 1, 0.0, prefix_length=60), log=log)
+    bases, offsets = oracle.concat_reads([x for _, x in recs])
+    keep, _, _ = oracle.filter_batch(index, bases, offsets, None, 1, 0.0, 60, False)
+    assert s["seqs_out"] == int(keep.sum()) and s["prefix_length"] == 316
+    assert "modulo 256 = 60" in log.getvalue()
+
+
+@pytest.mark.gpu
+def test_gpu_client_command_file_to_file(gpu_server, oracle, tmp_path, capsys):
+    from deacon_server_amd import client as CL
+    srv, url, index, reads = gpu_server
+    recs = _named(reads)
+    (tmp_path / "in.fq").write_bytes(_fastq_bytes(recs))
+    for deplete in (False, True):
+        argv = [url, str(tmp_path / "in.fq"), "-o", str(tmp_path / "out.fq"), "-s", str(tmp_path / "s.json"), "-p", "120"]
+        assert CL.main(argv + (["-d"] if deplete else [])) == 0
+        bases, offsets = oracle.concat_reads([s for _, s in recs])
+        keep, hits, total = oracle.filter_batch(index, bases, offsets, None, 2, 0.01, 120, deplete)
+        assert (tmp_path / "out.fq").read_bytes() == _fastq_bytes([r for r, k in zip(recs, keep) if k])
+        summary = json.loads((tmp_path / "s.json").read_text())
+        assert summary["seqs_out"] == int(keep.sum()) and summary["prefix_length"] == 120 and summary["deplete"] is deplete
+    assert "Retained " in capsys.readouterr().err
+    assert CL.main(["http://127.0.0.1:9", str(tmp_path / "in.fq")]) == 1  # nobody listens there: an error, not a traceback

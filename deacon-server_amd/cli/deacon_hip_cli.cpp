@@ -430,20 +430,25 @@ class Input {
 class Output {
   public:
     enum Codec { PLAIN, GZIP, ZSTD, XZ };
-    Output(const std::string &path, int level) : level_(level) {
+    // the codec an output path asks for by its extension, with the level and the library checked (dies otherwise)
+    static Codec check_level(const std::string &path, int level) {
         std::string why;
         if (ends_with(path, ".gz")) {
             if (level < 1 || level > 9) die("Invalid gzip compression level " + std::to_string(level) + ". Must be between 1 and 9.");
-            codec_ = GZIP;
+            return GZIP;
         } else if (ends_with(path, ".zst")) {
             if (level < 1 || level > 22) die("Invalid zstd compression level " + std::to_string(level) + ". Must be between 1 and 22.");
             if (!codecs::Zstd::get(&why)) die("zstd output " + path + ": " + why);
-            codec_ = ZSTD;
+            return ZSTD;
         } else if (ends_with(path, ".xz")) {
             if (level < 0 || level > 9) die("Invalid xz compression level " + std::to_string(level) + ". Must be between 0 and 9.");
             if (!codecs::Lzma::get(&why)) die("xz output " + path + ": " + why);
-            codec_ = XZ;
+            return XZ;
         }
+        return PLAIN;
+    }
+    Output(const std::string &path, int level) : level_(level) {
+        codec_ = check_level(path, level);
         if (path == "-") {
             f_ = stdout;
         } else {
@@ -3116,6 +3121,35 @@ int main(int argc, char **argv) {
             }
             const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::fprintf(stderr, "decoded %llu bytes in %.3f s: %.2f GB/s\n", (unsigned long long)total, sec, total / sec / 1e9);
+            return 0;
+        }
+        if (args[0] == "compress" && args.size() >= 2) {  // hidden: a writer alone, streaming (stdin -> members / frames of gz | zst | xz on
+                                                          // stdout; no GPU): compress <codec> [level].  The Python client's .zst outputs.
+            const int level = args.size() >= 3 ? std::atoi(args[2].c_str()) : 2;
+            const std::string fake = "x." + args[1];
+            Output::Codec codec;
+            if (args[1] == "gz") codec = Output::GZIP;
+            else if (args[1] == "zst") codec = Output::ZSTD;
+            else if (args[1] == "xz") codec = Output::XZ;
+            else die("compress: codec must be gz, zst or xz");
+            Output::check_level(fake, level);
+            std::vector<char> buf(8u << 20), piece;
+            size_t have = 0, total = 0;
+            auto flush_piece = [&](size_t n) {
+                Output::compress_member(codec, level, buf.data(), n, piece);
+                for (size_t w = 0; w < piece.size();) {
+                    const ssize_t r = ::write(1, piece.data() + w, piece.size() - w);
+                    if (r < 0) die("write error");
+                    w += (size_t)r;
+                }
+            };
+            for (ssize_t r; (r = ::read(0, buf.data() + have, buf.size() - have)) > 0;) {
+                have += (size_t)r;
+                total += (size_t)r;
+                if (have == buf.size()) flush_piece(have), have = 0;
+            }
+            if (have || codec != Output::GZIP || total == 0) flush_piece(have);  // (an empty input is still one valid empty frame)
+            if (codec == Output::GZIP && total != 0) flush_piece(0);          // BGZF's end-of-file member
             return 0;
         }
         if (args[0] == "gz" && args.size() >= 1) {  // hidden: the .gz writer alone (stdin -> BGZF members on stdout; no GPU): gz [level]

@@ -152,7 +152,7 @@ def _open_input(path):
     if kind == "xz":
         return io.BufferedReader(lzma.LZMAFile(raw))
     if kind == "zst":
-        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "deacon-hip")
+        tool = _tool()
         if path == "-" or not os.path.exists(tool):
             raise ClientError("zstd input needs a file path and the deacon-hip tool beside this package")
         raw.close()
@@ -202,20 +202,51 @@ def read_fastx(stream):
             raise ClientError(f"Record {n} starts with neither '>' nor '@'")
 
 
+def _tool():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "deacon-hip")
+
+
+class _ToolCompressor:
+    """A .zst output: this Python has no zstd, so the records go through the tool's own writer (`deacon-hip compress zst LEVEL`,
+    a child process that never touches the GPU) into the file."""
+
+    def __init__(self, path, kind, level):
+        self._file = open(path, "wb")
+        self._proc = subprocess.Popen([_tool(), "compress", kind, str(level)], stdin=subprocess.PIPE, stdout=self._file)
+
+    def write(self, data):
+        self._proc.stdin.write(data)
+
+    def flush(self):
+        self._proc.stdin.flush()
+
+    def close(self):
+        self._proc.stdin.close()
+        rc = self._proc.wait()
+        self._file.close()
+        if rc != 0:
+            raise ClientError(f"the compressor of {self._file.name} failed (exit code {rc})")
+
+
 def _open_output(path, level):
-    """get_writer (remote_filter.rs:189-228): the extension chooses the codec, the level is checked against it."""
+    """get_writer (remote_filter.rs:189-228): the extension chooses the codec, the level is checked against it
+    (validate_compression_level, :66-100)."""
     if path == "-":
         return sys.stdout.buffer
     if path.endswith(".gz"):
         if not 1 <= level <= 9:
-            raise ClientError(f"Invalid compression level {level} for gzip: must be 1-9")
+            raise ClientError(f"Invalid gzip compression level {level}. Must be between 1 and 9.")
         return gzip.open(path, "wb", compresslevel=level)
     if path.endswith(".xz"):
         if not 0 <= level <= 9:
-            raise ClientError(f"Invalid compression level {level} for xz: must be 0-9")
+            raise ClientError(f"Invalid xz compression level {level}. Must be between 0 and 9.")
         return lzma.open(path, "wb", preset=level)
     if path.endswith(".zst"):
-        raise ClientError("zstd output is not available in this client (no zstd in this Python); use .gz, .xz or plain")
+        if not 1 <= level <= 22:
+            raise ClientError(f"Invalid zstd compression level {level}. Must be between 1 and 22.")
+        if not os.path.exists(_tool()):
+            raise ClientError("zstd output needs the deacon-hip tool beside this package (build it: __graft_entry__.build())")
+        return _ToolCompressor(path, "zst", level)
     return open(path, "wb")
 
 
@@ -375,7 +406,7 @@ def main(argv=None):
     ap.add_argument("server_address", help="Server address to connect to (including port), e.g. http://127.0.0.1:8888")
     ap.add_argument("input", nargs="?", default="-", help="Optional path to fastx file (or - for stdin)")
     ap.add_argument("input2", nargs="?", default=None, help="Optional path to second paired fastx file (or - for interleaved stdin)")
-    ap.add_argument("-o", "--output", default="-", help="Path to output fastx file (or - for stdout; detects .gz and .xz)")
+    ap.add_argument("-o", "--output", default="-", help="Path to output fastx file (or - for stdout; detects .gz, .zst and .xz)")
     ap.add_argument("-O", "--output2", default=None, help="Optional path to second paired output fastx file")
     ap.add_argument("-a", "--abs-threshold", type=int, default=2, help="Minimum absolute number of minimizer hits for a match")
     ap.add_argument("-r", "--rel-threshold", type=float, default=0.01, help="Minimum relative proportion (0.0-1.0) of minimizer hits for a match")
@@ -384,7 +415,7 @@ def main(argv=None):
     ap.add_argument("-R", "--rename", action="store_true", help="Replace sequence headers with incrementing numbers")
     ap.add_argument("-s", "--summary", default=None, help="Path to JSON summary output file")
     ap.add_argument("-t", "--threads", type=int, default=8, help="Accepted for compatibility (the minimizers are the GPU's)")
-    ap.add_argument("--compression-level", type=int, default=2, help="Output compression level (1-9 for gz & xz)")
+    ap.add_argument("--compression-level", type=int, default=2, help="Output compression level (1-9 for gz & xz; 1-22 for zstd)")
     ap.add_argument("--debug", action="store_true", help="Output sequences with minimizer hits to stderr")
     ap.add_argument("-q", "--quiet", action="store_true", help="Suppress progress reporting")
     ap.add_argument("--device", type=int, default=0, help="GPU that computes the minimizers")
@@ -393,6 +424,8 @@ def main(argv=None):
         ap.error("invalid value for --abs-threshold: must be 1..65535")
     if a.prefix_length < 0:
         ap.error("invalid value for --prefix-length")
+    if a.output2 is not None and a.input2 is None:  # src/main.rs:385-389
+        sys.stderr.write("Warning: --output2 specified but no second input file provided. --output2 will be ignored.\n")
     try:
         run_client(a.server_address, a.input, a.input2, a.output, a.output2, a.abs_threshold, a.rel_threshold, a.prefix_length,
                    a.deplete, a.rename, a.summary, a.threads, a.compression_level, a.debug, a.quiet, a.device)

@@ -272,16 +272,35 @@ def test_read_fastx_shapes():
     assert list(CL.read_fastx(io.BytesIO(b""))) == []
 
 
-@pytest.mark.parametrize("deplete,rename,gz", [(False, False, False), (True, True, False), (False, True, True)])
-def test_client_command_single_over_http(oracle_server, oracle, tmp_path, deplete, rename, gz):
+def _decoded(path):
+    """any compressed file -> bytes, through the tool's own reader (no GPU involved)"""
+    import os
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "deacon-server_amd", "bin", "deacon-hip")
+    return subprocess.run([tool, "cat", str(path)], check=True, capture_output=True).stdout
+
+
+# server_tests.rs:148-410 (the client command to a file, .gz / .zst / .xz by extension, --deplete, --rename) with the outputs
+# checked byte for byte instead of for existence
+@pytest.mark.parametrize("deplete,rename,ext", [(False, False, ""), (True, True, ""), (False, True, ".gz"), (False, False, ".zst"),
+                                                (True, False, ".xz")])
+def test_client_command_single_over_http(oracle_server, oracle, tmp_path, deplete, rename, ext):
     import gzip
     import io
+    import subprocess
     from deacon_server_amd import client as CL
     srv, url, index, reads, path = oracle_server
     recs = _named(reads)
-    inp = tmp_path / ("in.fastq.gz" if gz else "in.fastq")
-    inp.write_bytes(gzip.compress(_fastq_bytes(recs)) if gz else _fastq_bytes(recs))
-    out = tmp_path / ("out.fastq.gz" if gz else "out.fastq")
+    gz = ext != ""
+    inp = tmp_path / ("in.fastq" + ext)
+    if ext == ".gz":
+        inp.write_bytes(gzip.compress(_fastq_bytes(recs)))
+    elif ext:  # written by the tool's own writer, read back by the client (zstd through `deacon-hip cat`, xz through lzma)
+        inp.write_bytes(subprocess.run([CL._tool(), "compress", ext[1:], "3"], input=_fastq_bytes(recs), check=True,
+                                       capture_output=True).stdout)
+    else:
+        inp.write_bytes(_fastq_bytes(recs))
+    out = tmp_path / ("out.fastq" + ext)
     log = io.StringIO()
     summary = CL.run_client(url, str(inp), None, str(out), None, 2, 0.01, 0, deplete, rename, str(tmp_path / "s.json"),
                             remote_filter=_oracle_remote_filter(CL, oracle, url, deplete=deplete), log=log)
@@ -290,8 +309,9 @@ def test_client_command_single_over_http(oracle_server, oracle, tmp_path, deplet
     kept = [(i, s) for (i, s), k in zip(recs, keep) if k]
     assert 0 < len(kept) < len(recs)
     want = _fastq_bytes([(str(n + 1).encode(), s) if rename else (i, s) for n, (i, s) in enumerate(kept)])
-    got = out.read_bytes()
-    assert (gzip.decompress(got) if gz else got) == want
+    assert (_decoded(out) if gz else out.read_bytes()) == want
+    if ext == ".gz":
+        assert gzip.decompress(out.read_bytes()) == want
     assert summary == {**json.loads((tmp_path / "s.json").read_text())}
     assert (summary["seqs_in"], summary["seqs_out"], summary["seqs_removed"]) == (len(recs), len(kept), len(recs) - len(kept))
     assert summary["bp_in"] == sum(len(s) for _, s in recs) and summary["bp_out"] == sum(len(s) for _, s in kept)
@@ -351,6 +371,19 @@ def test_client_command_pairs_over_http(oracle_server, oracle, tmp_path, monkeyp
         CL.run_client(url, "-", "-", str(tmp_path / "j.fq"), None, remote_filter=_oracle_remote_filter(CL, oracle, url), log=io.StringIO())
 
 
+def test_client_command_refuses_levels_like_the_reference(oracle_server, oracle, tmp_path):  # remote_filter.rs:66-100
+    import io
+    from deacon_server_amd import client as CL
+    srv, url, index, reads, path = oracle_server
+    (tmp_path / "in.fq").write_bytes(_fastq_bytes(_named(reads)))
+    for name, level, text in (("o.fq.gz", 10, "Invalid gzip compression level 10. Must be between 1 and 9."),
+                              ("o.fq.zst", 23, "Invalid zstd compression level 23. Must be between 1 and 22."),
+                              ("o.fq.xz", 10, "Invalid xz compression level 10. Must be between 0 and 9.")):
+        with pytest.raises(CL.ClientError, match=text):
+            CL.run_client(url, str(tmp_path / "in.fq"), None, str(tmp_path / name), None, compression_level=level,
+                          remote_filter=_oracle_remote_filter(CL, oracle, url), log=io.StringIO())
+
+
 def test_client_command_prefix_is_a_u8_like_the_reference(oracle_server, oracle, tmp_path):
     import io
     from deacon_server_amd import client as CL
@@ -381,4 +414,21 @@ def test_gpu_client_command_file_to_file(gpu_server, oracle, tmp_path, capsys):
         summary = json.loads((tmp_path / "s.json").read_text())
         assert summary["seqs_out"] == int(keep.sum()) and summary["prefix_length"] == 120 and summary["deplete"] is deplete
     assert "Retained " in capsys.readouterr().err
+    # -O without a second input: a warning, no second file (server_tests.rs:992-1026)
+    assert CL.main([url, str(tmp_path / "in.fq"), "-o", str(tmp_path / "o1.fq"), "-O", str(tmp_path / "o2.fq")]) == 0
+    assert "Warning: --output2 specified but no second input" in capsys.readouterr().err
+    assert (tmp_path / "o1.fq").exists() and not (tmp_path / "o2.fq").exists()
+    # two files of mates, two outputs, one of them .zst (server_tests.rs:413-450, :870-990)
+    pairs = recs[:len(recs) // 2 * 2]
+    (tmp_path / "r1.fq").write_bytes(_fastq_bytes(pairs[0::2]))
+    (tmp_path / "r2.fq").write_bytes(_fastq_bytes(pairs[1::2]))
+    assert CL.main([url, str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"), "-o", str(tmp_path / "p1.fq"), "-O",
+                    str(tmp_path / "p2.fq.zst"), "-d", "-R"]) == 0
+    bases, offsets = oracle.concat_reads([s for _, s in pairs])
+    unit_id = (np.arange(len(pairs)) // 2).astype(np.uint32)
+    keep, _, _ = oracle.filter_batch(index, bases, offsets, unit_id, 2, 0.01, 0, True)
+    kept = [j for j, k in enumerate(keep) if k]
+    assert 0 < len(kept) < len(keep)
+    assert (tmp_path / "p1.fq").read_bytes() == _fastq_bytes([(str(2 * n + 1).encode(), pairs[2 * j][1]) for n, j in enumerate(kept)])
+    assert _decoded(tmp_path / "p2.fq.zst") == _fastq_bytes([(str(2 * n + 2).encode(), pairs[2 * j + 1][1]) for n, j in enumerate(kept)])
     assert CL.main(["http://127.0.0.1:9", str(tmp_path / "in.fq")]) == 1  # nobody listens there: an error, not a traceback

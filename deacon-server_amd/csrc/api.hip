@@ -308,6 +308,24 @@ extern "C" int dcn_index_clone(const dcn_index *index, int device, dcn_index **o
     idx->device = device;
     idx->d_slots = nullptr;
     const uint64_t bytes = idx->n_groups * DCN_GROUP_SLOTS * sizeof(uint64_t);
+    // Another GPU: the keys cross the link, not the table (a tenth of the bytes at the default 8 slots per key; dcn_table_clone_by_keys).
+    // The same GPU: a device-to-device copy of the table at HBM's pace.  DCN_CLONE_BY_KEYS=1 / DCN_CLONE_BY_COPY=1 force one form
+    // (the first is how the one-GPU tests reach the cross-device code).
+    const bool by_keys = std::getenv("DCN_CLONE_BY_KEYS") || (device != index->device && !std::getenv("DCN_CLONE_BY_COPY"));
+    if (by_keys) {
+        if (device != index->device) {
+            int can = 0;
+            if (hipSetDevice(device) == hipSuccess && hipDeviceCanAccessPeer(&can, device, index->device) == hipSuccess && can)
+                if (hipDeviceEnablePeerAccess(index->device, 0) != hipSuccess) (void)hipGetLastError(); // already enabled
+        }
+        const int rc = dcn_table_clone_by_keys(index, idx);
+        if (rc != DCN_OK) {
+            delete idx;
+            return rc;
+        }
+        *out = idx;
+        return DCN_OK;
+    }
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipMalloc((void **)&idx->d_slots, std::max<uint64_t>(bytes, 16));
     if (e == hipSuccess && bytes) {

@@ -619,6 +619,78 @@ int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity
     return DCN_OK;
 }
 
+// A replica on another GPU made from the KEYS instead of from the table: the table is sparse by design
+// (8-40 slots per key: 34 GB for panhuman-1's 3.3 GB of keys), and an xGMI link is what a peer copy is bound by.  The source
+// compacts its keys (the export kernel: the table streams by once, 10 ms), the compact array crosses the link (3.3 GB instead
+// of 34), the target inserts them into an empty table of the same geometry (one launch).  `dst` arrives with every field of
+// `src` copied, its own device set and d_slots null.  Membership, n_keys and has_zero are the source's; which slot of a group
+// a key sits in is not, and nothing observes that.
+int dcn_table_clone_by_keys(const dcn_index *src, dcn_index *dst) {
+    const uint64_t n_nonzero = src->n_keys - (src->has_zero ? 1 : 0);
+    const uint64_t table_bytes = src->n_groups * DCN_GROUP_SLOTS * sizeof(uint64_t);
+    uint64_t *d_src_keys = nullptr, *d_dst_keys = nullptr;
+    unsigned long long *d_cur = nullptr, *d_new = nullptr;
+    uint32_t *d_zero = nullptr;
+    hipError_t e = hipSetDevice(src->device);
+    if (e == hipSuccess && n_nonzero) {
+        e = hipMalloc((void **)&d_src_keys, n_nonzero * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_cur, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMemset(d_cur, 0, sizeof(unsigned long long));
+        if (e == hipSuccess) {
+            const uint64_t n_slots = src->n_groups * DCN_GROUP_SLOTS;
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_slots + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(export_keys_kernel, dim3(blocks), dim3(256), 0, 0, src->d_slots, n_slots, d_src_keys, n_nonzero, d_cur);
+            e = hipGetLastError();
+        }
+        unsigned long long found = 0;
+        if (e == hipSuccess) e = hipMemcpy(&found, d_cur, sizeof(found), hipMemcpyDeviceToHost);  // (also the kernel's end)
+        if (e == hipSuccess && found != n_nonzero) {
+            hipFree(d_src_keys);
+            hipFree(d_cur);
+            return dcn_fail(DCN_ERR_HIP, "index clone: the table holds " + std::to_string(found) + " keys, its header says " + std::to_string(n_nonzero));
+        }
+    }
+    if (e == hipSuccess) e = hipSetDevice(dst->device);
+    if (e == hipSuccess) e = hipMalloc((void **)&dst->d_slots, std::max<uint64_t>(table_bytes, 16));
+    if (e == hipSuccess && table_bytes) e = hipMemsetAsync(dst->d_slots, 0, table_bytes, 0);
+    if (e == hipSuccess && n_nonzero) {
+        e = hipMalloc((void **)&d_dst_keys, n_nonzero * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemcpyPeer(d_dst_keys, dst->device, d_src_keys, src->device, n_nonzero * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_new, sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_zero, sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(d_new, 0, sizeof(unsigned long long), 0);
+        if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, sizeof(uint32_t), 0);
+        if (e == hipSuccess) {
+            const dcn_table_view v = dst->view();
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_nonzero + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL(table_insert_kernel<false>, dim3(blocks), dim3(256), 0, 0, dst->d_slots, v.group_shift, v.group_mask,
+                               d_dst_keys, n_nonzero, d_new, d_zero);
+            e = hipGetLastError();
+        }
+        unsigned long long inserted = 0;
+        if (e == hipSuccess) e = hipMemcpy(&inserted, d_new, sizeof(inserted), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && inserted != n_nonzero) {
+            e = hipErrorUnknown;
+            (void)dcn_fail(DCN_ERR_HIP, "index clone: " + std::to_string(inserted) + " of " + std::to_string(n_nonzero) + " keys arrived");
+        }
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (d_dst_keys) hipFree(d_dst_keys);
+    if (d_new) hipFree(d_new);
+    if (d_zero) hipFree(d_zero);
+    (void)hipSetDevice(src->device);
+    if (d_src_keys) hipFree(d_src_keys);
+    if (d_cur) hipFree(d_cur);
+    if (e != hipSuccess) {
+        (void)hipSetDevice(dst->device);
+        if (dst->d_slots) hipFree(dst->d_slots);
+        dst->d_slots = nullptr;
+        if (e == hipErrorUnknown) return DCN_ERR_HIP;  // (message set above)
+        return dcn_fail(e == hipErrorOutOfMemory ? DCN_ERR_NOMEM : DCN_ERR_HIP, std::string("index clone by keys: ") + hipGetErrorString(e));
+    }
+    return DCN_OK;
+}
+
 // ----------------------------------------------------------------------------------------------------
 // set algebra on device tables (f4 of SURVEY.md 8f): index::union (src/index.rs:563-664), index::diff (:421-536)
 // ----------------------------------------------------------------------------------------------------

@@ -154,9 +154,11 @@ int dcn_index_contains_device(const dcn_index *index, const uint64_t *d_keys, ui
 int dcn_index_probe_ceiling(const dcn_index *index, const uint64_t *d_keys, uint64_t n, uint32_t reps,
                             double *probes_per_s);
 
-/* Replica of an index on another (or the same) device, copied device to device (hipMemcpyPeer over xGMI): the
- * reference shares ONE set between its workers through an Arc (src/local_filter.rs:630-631); a multi-GPU host
- * loads or builds the index once and clones it to every other device instead of repeating the host-to-device copy. */
+/* Replica of an index on another (or the same) device, made device to device: the reference shares ONE set between its
+ * workers through an Arc (src/local_filter.rs:630-631); a multi-GPU host loads or builds the index once and clones it to
+ * every other device instead of repeating the host-to-device copy.  To another device the compacted KEYS cross xGMI
+ * (hipMemcpyPeer of 8 bytes per key, a tenth of the sparse table) and are inserted into an empty table there; on the same
+ * device the table itself is copied.  Same key set, k, w and minimizer rule either way. */
 int dcn_index_clone(const dcn_index *index, int device, dcn_index **out);
 
 void dcn_index_destroy(dcn_index *index);

@@ -381,6 +381,30 @@ def test_index_clone_and_stats_allreduce(oracle, dcn, genome, index_pair):
         gidx.clone(99)
 
 
+@pytest.mark.parametrize("n_keys", [0, 1, 200_000])
+def test_index_clone_by_keys_is_the_same_set(oracle, dcn, n_keys, monkeypatch):
+    """A replica on ANOTHER GPU is made from the compacted keys (a tenth of the table's bytes over xGMI), not from the table:
+    dcn_table_clone_by_keys.  On the one-GPU box DCN_CLONE_BY_KEYS=1 sends a same-device clone down that path (export kernel,
+    peer copy of the key array, insert into an empty table of the same geometry): same header, same key set (incl. key 0),
+    same answers; the copy form beside it."""
+    rng = np.random.default_rng(141 + n_keys)
+    keys = np.unique(rng.integers(1, 2**63, n_keys, dtype=np.int64).astype(np.uint64))
+    if n_keys > 1:
+        keys = np.concatenate([keys, np.array([0, 2**64 - 1], np.uint64)])  # key 0 lives in a flag, not in a slot
+    src = dcn.Index.from_keys(keys, 31, 15, device=0)
+    monkeypatch.setenv("DCN_CLONE_BY_KEYS", "1")
+    by_keys = src.clone(0)
+    monkeypatch.delenv("DCN_CLONE_BY_KEYS")
+    by_copy = src.clone(0)
+    probe = np.concatenate([keys, keys ^ np.uint64(1), rng.integers(0, 2**63, 1000, dtype=np.int64).astype(np.uint64)])
+    for rep in (by_keys, by_copy):
+        assert rep.header() == src.header() and rep.n_keys == len(keys)
+        assert sorted(rep.keys().tolist()) == sorted(keys.tolist())
+        assert rep.contains(probe).tolist() == src.contains(probe).tolist()
+        rep.close()
+    src.close()
+
+
 def test_contexts_on_several_threads_pack_side_by_side(oracle, dcn, genome, index_pair, monkeypatch):
     """Round 4: the host pool runs the jobs of several contexts at a time.  Three contexts, each on its
     own thread, each filtering its own pageable batches cut into dozens of chunks (so their packing jobs interleave on the

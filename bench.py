@@ -1208,10 +1208,8 @@ def main():
         except Exception as ex:  # every rank fails or none does (same code, same sizes); never take the line with it
             log(f"host_path at N = {world} failed: {ex!r}")
             host_path_all = {"error": repr(ex)}
-    if world > 1 and not args.pmc_child:  # (the last thing the ranks do together: see c_abi_rccl_check)
-        collective["c_abi_rccl"] = c_abi_rccl_check(index, batches[0], params, world, device, coll_device)
-        if collective["c_abi_rccl"] and "matches_torch_all_reduce" in collective["c_abi_rccl"]:
-            collective["c_abi_rccl_matches"] = collective["c_abi_rccl"]["matches_torch_all_reduce"]
+    if world > 1 and not args.pmc_child:
+        collective["c_abi_rccl"] = "checked after the line is printed: stderr and bench_detail.json carry the result"
     if rank == 0:
         total_bp = counters["total_bp"]
         rf = head["roofline"]
@@ -1451,8 +1449,26 @@ def main():
             out["cli"] = cli
         out["bench_wall_s"] = time.time() - T0
         emit(out, args.detail)
+    if world > 1 and not args.pmc_child:
+        # The LAST thing the ranks do together, AFTER rank 0 has printed the line: the C ABI's own RCCL communicator has never met
+        # more than one device before the driver's scaling run, and nothing it does (a fault inside the library included) may
+        # cost that run its line.  Result: stderr, and `collective.c_abi_rccl` of bench_detail.json.
+        res = c_abi_rccl_check(index, batches[0], params, world, device, coll_device)
+        collective["c_abi_rccl"] = res
+        if rank == 0:
+            log(f"C-ABI RCCL all-reduce of the counters over {world} ranks (dcn_comm_* / dcn_stats_allreduce_rccl): {json.dumps(res, default=str)}")
+            try:
+                if args.detail and os.path.exists(args.detail):
+                    det = json.load(open(args.detail))
+                    det.setdefault("collective", {})["c_abi_rccl"] = res
+                    if res and "matches_torch_all_reduce" in res:
+                        det["collective"]["c_abi_rccl_matches"] = res["matches_torch_all_reduce"]
+                    with open(args.detail, "w") as f:
+                        json.dump(det, f, indent=1, default=str)
+            except Exception as ex:  # noqa: BLE001
+                log(f"could not add the C-ABI RCCL result to {args.detail}: {ex!r}")
     if world > 1:
-        if (collective.get("c_abi_rccl") or {}).get("timed_out"):  # a helper thread is still inside RCCL: no further collective,
+        if isinstance(collective.get("c_abi_rccl"), dict) and collective["c_abi_rccl"].get("timed_out"):  # a helper thread is still inside RCCL: no further collective,
             sys.stdout.flush()                                      # no orderly teardown around it
             sys.stderr.flush()
             os._exit(0)

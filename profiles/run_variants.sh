@@ -1,9 +1,9 @@
 #!/bin/bash
-# time the scan stage for each experiment variant: profiles/run_variants.sh "<bench args>" name1 name2 ...
+# time the scan stage for each experiment variant (the full result is read from bench.py's --detail file; stdout carries the compact line): profiles/run_variants.sh "<bench args>" name1 name2 ...
 ARGS=$1; shift
 for v in "$@"; do
   if [ "$v" = base ]; then lib=""; else lib="$GRAFT_REPO_ROOT/deacon-server_amd/lib/variants/libdeacon_hip_$v.so"; fi
-  DCN_LIB_PATH=$lib timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --no-extras > gpurun_out/var_$v.json 2> gpurun_out/var_$v.err || echo "$v FAILED"
+  DCN_LIB_PATH=$lib timeout -k 10 300 python bench.py $ARGS --no-cpu-baseline --no-extras --detail gpurun_out/var_$v.json > gpurun_out/var_$v.line 2> gpurun_out/var_$v.err || echo "$v FAILED"
   python - "$v" <<'PY'
 import json,sys
 v=sys.argv[1]

@@ -92,3 +92,24 @@ def test_callers_on_several_threads_share_the_host_pool(dcn):
         th.join(timeout=300)
         assert not th.is_alive(), "a caller never got its job back from the pool"
     assert not errors, errors
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_host_pool_under_the_sanitizers(tmp_path, sanitizer):
+    """tests/cpp/host_pool_test.cpp: the pool that runs several contexts' jobs side by side (csrc/dcn_host_pool.h, plain C++)
+    under ThreadSanitizer and AddressSanitizer / UBSan on the CPU -- six caller threads with 1,500 jobs each (slices claimed by
+    compare-exchange, workers going to sleep and waking), then more callers than the pool has slots."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host_pool_test"
+    p = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all",
+                        "-I", os.path.join(root, "deacon-server_amd", "csrc"), "-o", str(exe),
+                        os.path.join(root, "tests", "cpp", "host_pool_test.cpp")], capture_output=True, text=True)
+    if p.returncode != 0 and "sanitize" in p.stderr.lower():
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert p.returncode == 0, p.stderr[-2000:]
+    for env in (dict(os.environ, DCN_HOST_THREADS="6"), dict(os.environ)):
+        env.pop("DCN_HOST_SPIN_US", None)
+        r = subprocess.run([str(exe)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("bad 0"), (r.stdout[-300:], r.stderr[-3000:])

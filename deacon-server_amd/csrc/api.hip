@@ -328,7 +328,7 @@ extern "C" int dcn_index_clone(const dcn_index *index, int device, dcn_index **o
         return DCN_OK;
     }
     hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipMalloc((void **)&idx->d_slots, std::max<uint64_t>(bytes, 16));
+    if (e == hipSuccess) e = dcn_table_malloc(&idx->d_slots, std::max<uint64_t>(bytes, 16));
     if (e == hipSuccess && bytes) {
         if (device == index->device) {
             e = hipMemcpy(idx->d_slots, index->d_slots, bytes, hipMemcpyDeviceToDevice);

@@ -212,6 +212,7 @@ int dcn_table_insert_dump(dcn_index *idx, const uint64_t *d_hash, const uint8_t 
 int dcn_table_count_valid(const uint8_t *d_valid, uint64_t n, uint64_t *count, hipStream_t stream);
 int dcn_table_export(const dcn_index *idx, uint64_t *host_out, uint64_t capacity, uint64_t *n_out);
 int dcn_table_merge(dcn_index *dst, const dcn_index *src, const dcn_index *minus);
+hipError_t dcn_table_malloc(uint64_t **p, uint64_t bytes);                            // the table's allocation (DCN_TABLE_CONTIGUOUS=1: physically contiguous)
 int dcn_table_clone_by_keys(const dcn_index *src, dcn_index *dst);              // replica on dst->device from the compacted keys
 
 

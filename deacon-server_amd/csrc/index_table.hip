@@ -137,12 +137,27 @@ __global__ void table_contains_kernel(dcn_table_view t, const uint64_t *keys, ui
 }
 } // namespace
 
+// The table's allocation.  DCN_TABLE_CONTIGUOUS=1 (experiment, profiles/r04_ab.txt section 8) asks the runtime for physically
+// contiguous memory -- the scan kernel's time moves by up to 8 % with where the 34 GB table landed (profiles/r03_placement.txt) --
+// and falls back to the plain allocation when that is refused.
+hipError_t dcn_table_malloc(uint64_t **p, uint64_t bytes) {
+    static const bool contiguous = getenv("DCN_TABLE_CONTIGUOUS") != nullptr;
+    if (contiguous) {
+        if (hipExtMallocWithFlags((void **)p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+        static bool said = false;
+        if (!said) fprintf(stderr, "deacon-hip: no contiguous allocation of %llu bytes for the table; plain hipMalloc\n", (unsigned long long)bytes);
+        said = true;
+    }
+    return hipMalloc((void **)p, bytes);
+}
+
 int dcn_table_build(dcn_index *idx, const uint64_t *host_keys, uint64_t n) {
     DCN_HIP(hipSetDevice(idx->device));
     uint64_t groups = dcn_table_groups_for(n);
     if (groups > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
     idx->n_groups = groups;
-    DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    DCN_HIP(dcn_table_malloc(&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     DCN_HIP(hipMemset(idx->d_slots, 0, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     unsigned long long *d_new = nullptr;
     uint32_t *d_zero = nullptr;
@@ -455,7 +470,7 @@ int dcn_table_alloc(dcn_index *idx, uint64_t n_keys_capacity) {
     uint64_t groups = dcn_table_groups_for(n_keys_capacity);
     if (groups > (1ull << 32)) return dcn_fail(DCN_ERR_CAPACITY, "index too large for 2^32 groups");
     idx->n_groups = groups;
-    DCN_HIP(hipMalloc((void **)&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    DCN_HIP(dcn_table_malloc(&idx->d_slots, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     DCN_HIP(hipMemset(idx->d_slots, 0, groups * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     // the memset runs on the null stream without waiting for the host, and the callers' streams are non-blocking
     // (they do not wait for the null stream): the table must be clear before anyone inserts or probes
@@ -477,7 +492,7 @@ int dcn_table_reserve(dcn_index *idx, uint64_t n_keys_capacity) {
     bool keep_zero = idx->has_zero;
     idx->d_slots = nullptr;
     idx->n_groups = want;
-    DCN_HIP(hipMalloc((void **)&idx->d_slots, want * DCN_GROUP_SLOTS * sizeof(uint64_t)));
+    DCN_HIP(dcn_table_malloc(&idx->d_slots, want * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     DCN_HIP(hipMemset(idx->d_slots, 0, want * DCN_GROUP_SLOTS * sizeof(uint64_t)));
     unsigned long long *d_new = nullptr;
     uint32_t *d_zero = nullptr;
@@ -651,7 +666,7 @@ int dcn_table_clone_by_keys(const dcn_index *src, dcn_index *dst) {
         }
     }
     if (e == hipSuccess) e = hipSetDevice(dst->device);
-    if (e == hipSuccess) e = hipMalloc((void **)&dst->d_slots, std::max<uint64_t>(table_bytes, 16));
+    if (e == hipSuccess) e = dcn_table_malloc(&dst->d_slots, std::max<uint64_t>(table_bytes, 16));
     if (e == hipSuccess && table_bytes) e = hipMemsetAsync(dst->d_slots, 0, table_bytes, 0);
     if (e == hipSuccess && n_nonzero) {
         e = hipMalloc((void **)&d_dst_keys, n_nonzero * sizeof(uint64_t));

@@ -760,6 +760,9 @@ int enqueue_batch(dcn_ctx *c, const BatchView &v, const dcn_params *params, bool
     pa.tiles = c->d_tiles;
     pa.status = c->d_status;
     pa.newline_flag = newline_flag;
+    pa.stream_bases = v.stream_bases;
+    pa.check_offsets = 1;
+    pa.max_tiles = c->max_tiles;
     DCN_TRY(dcn_launch_plan(pa, st));
     if (pack_ahead && c->pack_ahead_state == 1) DCN_HIP(hipEventRecord(c->plan_done, st));
     DCN_PROF_MARK(DCN_STAGE_PLAN);
@@ -911,6 +914,12 @@ int sync_and_check(dcn_ctx *c, uint64_t *needed_records) {
     if (c->h_report->bounds) {
         DCN_HIP(hipMemsetAsync(c->d_report, 0, offsetof(dcn_batch_report, stats), c->stream));
         return dcn_fail(DCN_ERR_INTERNAL, "scan kernel: index out of range in phase B (DCN_DEBUG_BOUNDS build)");
+    }
+    if (c->h_report->bad_offsets) {
+        DCN_HIP(hipMemsetAsync(c->d_report, 0, offsetof(dcn_batch_report, stats), c->stream));
+        return dcn_fail(DCN_ERR_ARG, "d_offsets of a batch since the last synchronize were not non-decreasing within [0, n_bases] when the "
+                                     "device read them (were they written, and ordered before the context's stream, when "
+                                     "dcn_filter_batch_device was called?): the outputs and counters of those batches are undefined");
     }
     if (c->h_report->overflow) {
         const uint64_t need = c->h_report->need;
@@ -1950,6 +1959,7 @@ int wait_impl(dcn_ctx *c, uint64_t ticket) {
         hipError_t e = hipEventSynchronize(sl.done);
         if (e != hipSuccess) return fail(dcn_fail(DCN_ERR_HIP, std::string("hipEventSynchronize: ") + hipGetErrorString(e)));
         if (sl.h_report->bounds) return fail(dcn_fail(DCN_ERR_INTERNAL, "scan kernel: index out of range in phase B (DCN_DEBUG_BOUNDS build)"));
+        if (sl.h_report->bad_offsets) return fail(dcn_fail(DCN_ERR_INTERNAL, "the device met offsets the host had validated as decreasing or beyond the batch"));
         if (!sl.h_report->overflow) break;
         // Some chunk dropped hit records.  Grow the scratch and run the batch's kernels again: its inputs are still
         // resident in the slot.  Everything else in flight is drained first, since the scratch is shared.

@@ -123,6 +123,7 @@ struct dcn_status {
     uint32_t any_newline;          // the pack kernel saw a '\n' byte: only then does planning probe read ends
     uint32_t bounds;               // DCN_DEBUG_BOUNDS builds: phase B met an index outside its list / its stream
     uint32_t run_overflow;         // a unit had more hits in one wave than its run of the record array holds (rec_shift > 0)
+    uint32_t bad_offsets;          // the plan kernel met offsets[r] > offsets[r+1] or offsets[r+1] > n_bases: those reads were planned as empty
     unsigned long long set_cursor; // distinct pass: slots handed out to the global per-unit hash sets
 };
 
@@ -133,6 +134,8 @@ struct dcn_batch_report {
                                            // truncated records and its counters were skipped.  Bit 0: the global sets'
                                            // scratch was too small; bit 1: a run of the record array was (rec_shift > 0)
     uint32_t bounds;                       // DCN_DEBUG_BOUNDS builds only: the scan kernel refused an out-of-range index
+    uint32_t bad_offsets;                  // the offsets array was not non-decreasing within [0, n_bases] when the plan kernel read it
+    uint32_t reserved_;
     unsigned long long need;               // record capacity (set slots / 4) that would have sufficed
     unsigned long long stats[DCN_N_STATS]; // the six ProcessingStats counters
 };

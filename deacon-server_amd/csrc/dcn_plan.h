@@ -24,6 +24,10 @@ struct dcn_plan_args {
     uint32_t *tile_read_pos; // null, or per tile the position of its scan_start in its read (minimizer dump)
     uint32_t *tile_cursor;      // global tile counter (= &status->n_tiles, zeroed per batch)
     dcn_status *status;
+    uint64_t stream_bases;      // check_offsets: every read must lie inside [0, stream_bases)
+    uint32_t max_tiles;         // check_offsets: capacity of tiles[] (offsets that pass read by read can still overlap)
+    uint32_t check_offsets;     // 1: a read whose offsets are decreasing or beyond the stream is planned as empty and reported
+                                // (status->bad_offsets) instead of being followed outside the batch's buffers
     const uint32_t *newline_flag; // null: status->any_newline; else the word the pack kernel of this batch wrote (it may have
                                   // run ahead of the batch's own status words: api.hip, pack one batch ahead)
 };

@@ -21,6 +21,10 @@ __device__ inline void write_tile(const dcn_plan_args &a, uint32_t first, uint32
                                   uint32_t unit, bool whole_unit = false) {
     uint32_t wstart = j * a.tile_windows;
     uint32_t carry = j > 0 ? 1u : 0u;
+    if (a.check_offsets && first + j >= a.max_tiles) { // reads that overlap (bad offsets that pass one by one): more tiles than
+        a.status->bad_offsets = 1;                      // the batch's bases can have; the scan kernel does not run then
+        return;
+    }
     dcn_tile t;
     t.scan_start = off + wstart - carry;
     t.unit = unit;
@@ -71,8 +75,14 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
         nwin[c] = 0;
         nt[c] = 0;
         if (r < a.n_reads) {
-            uint64_t off = a.offsets[r];
-            nwin[c] = effective_windows(ascii, off, a.offsets[r + 1] - off, a.prefix_length, a.k, a.k + a.w - 1);
+            uint64_t off = a.offsets[r], end = a.offsets[r + 1];
+            // (device-pointer API: nobody has looked at this array before -- an array that was not written yet when the
+            // kernel ran, say, must end in an error code, not in tiles that point outside the batch)
+            if (a.check_offsets && (end < off || end > a.stream_bases)) {
+                a.status->bad_offsets = 1;
+                end = off = 0;
+            }
+            nwin[c] = effective_windows(ascii, off, end - off, a.prefix_length, a.k, a.k + a.w - 1);
             nt[c] = (nwin[c] + a.tile_windows - 1) / a.tile_windows;
         }
         const bool single = two_classes && nt[c] == 1;
@@ -129,6 +139,10 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
         bool unit_head = true;
         if (a.unit_id) {
             u = a.unit_id[r] - a.unit_base;
+            if (a.check_offsets && u >= a.n_units) { // (as for the offsets: an id outside the batch's units ends in an error code)
+                a.status->bad_offsets = 1;
+                u = 0;
+            }
             unit_head = r == 0 || a.unit_id[r - 1] != a.unit_id[r];
             if (unit_head) a.unit_first_read[u] = r;
             if (r == a.n_reads - 1) a.unit_first_read[a.n_units] = a.n_reads;
@@ -166,7 +180,8 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
     for (uint32_t q = 0; q < n_long; ++q) {
         const uint32_t li = long_reads[q], lr = block_first + li;
         const uint32_t lnt = s_tiles[li], lfirst = s_first[li];
-        const uint32_t lu = a.unit_id ? a.unit_id[lr] - a.unit_base : lr;
+        uint32_t lu = a.unit_id ? a.unit_id[lr] - a.unit_base : lr;
+        if (a.check_offsets && lu >= a.n_units) lu = 0; // (flagged above)
         const uint64_t loff = a.offsets[lr];
         const uint32_t lnwin = effective_windows(ascii, loff, a.offsets[lr + 1] - loff, a.prefix_length, a.k, a.k + a.w - 1);
         for (uint32_t j = OWN + tid; j < lnt; j += blockDim.x) write_tile(a, lfirst, j, loff, lnwin, lu);
@@ -445,11 +460,14 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (state[q] != 2 && a.offsets) {
+        for (int q = 0; q < 4; ++q) {
+            o0[q] = o1[q] = 0;
+            // (bad_offsets: the read ranges of the units may be as wrong as the offsets; the counters are not written then)
+            if (state[q] != 2 && a.offsets && !a.status->bad_offsets) {
                 o0[q] = a.offsets[r0[q]];
                 o1[q] = a.offsets[r1[q]];
             }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (state[q] == 2) continue;
@@ -485,6 +503,10 @@ __global__ __launch_bounds__(256) void finish_kernel(dcn_finish_args a) {
         }
     }
     if (a.status->bounds && blockIdx.x == 0 && threadIdx.x == 0) a.report->bounds = a.status->bounds;
+    if (a.status->bad_offsets) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.report->bad_offsets = 1;
+        return; // (the counters would be sums over those offsets)
+    }
     if (a.status->rec_overflow || a.status->run_overflow) {
         // sticky: the status words are cleared before the next chunk, the report is read when the batch is waited for
         if (blockIdx.x == 0 && threadIdx.x == 0) {

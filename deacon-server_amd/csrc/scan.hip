@@ -177,7 +177,8 @@ __global__ __launch_bounds__(DCN_WAVE, FAST ? DCN_MIN_WAVES_FAST : DCN_MIN_WAVES
     extern __shared__ __align__(16) uint2 dyn_ring[]; // only for W == 0: [w][64] (lkey, rkey); VAR: [w][64] of two u64 keys
 
     const int lane = threadIdx.x;
-    const uint32_t NT = *a.n_tiles;
+    // (bad_offsets: the plan kernel refused the batch's offsets -- api.hip reports it at the next synchronize; its tiles are not looked at)
+    const uint32_t NT = a.status->bad_offsets ? 0u : *a.n_tiles;
     const uint32_t wave_first = blockIdx.x * DCN_WAVE;
     if (wave_first >= NT) return;
     const uint32_t k = a.k;

@@ -248,7 +248,11 @@ int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uin
 /* Same computation on inputs already resident in device memory (all pointers are DEVICE pointers on the
  * context's GPU; d_unit_id / d_hits / d_total may be NULL).  n_bases = offsets[n_reads], n_units = number
  * of units (n_reads when d_unit_id is NULL).  Enqueues on the context's stream and returns without
- * waiting; call dcn_ctx_synchronize() before reading the outputs. */
+ * waiting; call dcn_ctx_synchronize() before reading the outputs.  The arrays are read WHEN THE KERNELS RUN, on the
+ * context's stream: a producer on another stream must be ordered before it (event or synchronize).  Nothing on the
+ * host has seen d_offsets / d_unit_id, so the planning kernel checks them: a read with offsets[r] > offsets[r+1] or
+ * offsets[r+1] > n_bases, or a unit id outside the batch's units, is planned as empty and the next
+ * dcn_ctx_synchronize() returns DCN_ERR_ARG (never tiles that point outside the batch's buffers). */
 int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
                             const uint32_t *d_unit_id, uint32_t n_reads, uint64_t n_bases, uint32_t n_units,
                             const dcn_params *params, uint8_t *d_keep, uint32_t *d_hits, uint32_t *d_total);
@@ -256,7 +260,9 @@ int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, const uint64_t
 /* Wait for everything enqueued on the context by dcn_filter_batch_device; reports deferred errors of the device
  * pipeline.  DCN_ERR_CAPACITY: the hit-record scratch overflowed in SOME batch enqueued since the previous
  * synchronize (the flag is sticky across batches); results and counters of all of them are then unspecified:
- * dcn_ctx_reserve_records(), dcn_ctx_reset_stats() and enqueue them again. */
+ * dcn_ctx_reserve_records(), dcn_ctx_reset_stats() and enqueue them again.  DCN_ERR_ARG: the device found the
+ * d_offsets / d_unit_id of some batch since the previous synchronize inconsistent (see above); outputs and counters
+ * of those batches are undefined, the context itself stays usable (reported once). */
 int dcn_ctx_synchronize(dcn_ctx *ctx);
 
 /* Grow the scratch that holds (unit, hash) hit records of units spanning several tiles (long reads). */

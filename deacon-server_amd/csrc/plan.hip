@@ -139,9 +139,14 @@ __global__ __launch_bounds__(256) void plan_kernel(dcn_plan_args a) {
         bool unit_head = true;
         if (a.unit_id) {
             u = a.unit_id[r] - a.unit_base;
-            if (a.check_offsets && u >= a.n_units) { // (as for the offsets: an id outside the batch's units ends in an error code)
-                a.status->bad_offsets = 1;
-                u = 0;
+            if (a.check_offsets) { // (as for the offsets: ids that are not 0, 0|1, ... n_units - 1 end in an error code --
+                // an id outside the batch's units, and also a unit WITHOUT a read: its entry of unit_first_read would be a
+                // previous batch's, and the finish kernel would follow it into this batch's offsets)
+                const uint32_t prev = r ? a.unit_id[r - 1] : a.unit_base - 1u;
+                if (u >= a.n_units || a.unit_id[r] - prev > 1u || (r == a.n_reads - 1 && u != a.n_units - 1)) {
+                    a.status->bad_offsets = 1;
+                    if (u >= a.n_units) u = 0;
+                }
             }
             unit_head = r == 0 || a.unit_id[r - 1] != a.unit_id[r];
             if (unit_head) a.unit_first_read[u] = r;

@@ -251,8 +251,9 @@ int dcn_pack_ascii(const uint8_t *bases, uint64_t n_bases, uint32_t *packed, uin
  * waiting; call dcn_ctx_synchronize() before reading the outputs.  The arrays are read WHEN THE KERNELS RUN, on the
  * context's stream: a producer on another stream must be ordered before it (event or synchronize).  Nothing on the
  * host has seen d_offsets / d_unit_id, so the planning kernel checks them: a read with offsets[r] > offsets[r+1] or
- * offsets[r+1] > n_bases, or a unit id outside the batch's units, is planned as empty and the next
- * dcn_ctx_synchronize() returns DCN_ERR_ARG (never tiles that point outside the batch's buffers). */
+ * offsets[r+1] > n_bases is planned as empty, unit ids that are not 0, then equal or +1, ending at n_units - 1 are
+ * flagged, and the next dcn_ctx_synchronize() returns DCN_ERR_ARG (never tiles or read ranges that point outside
+ * the batch's buffers). */
 int dcn_filter_batch_device(dcn_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets,
                             const uint32_t *d_unit_id, uint32_t n_reads, uint64_t n_bases, uint32_t n_units,
                             const dcn_params *params, uint8_t *d_keep, uint32_t *d_hits, uint32_t *d_total);

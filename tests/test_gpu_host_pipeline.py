@@ -353,6 +353,37 @@ def test_device_pointer_batch_with_offsets_that_were_never_written(oracle, dcn, 
         assert d_h.cpu().numpy().tolist() == want[1].tolist(), name
         assert d_t.cpu().numpy().tolist() == want[2].tolist(), name
         assert proc.stats()["total_seqs"] == n and proc.stats()["total_bp"] == len(b), name
+    # unit ids nobody has looked at either: 0, then equal or +1, ending at n_units - 1 -- anything else is refused
+    uid = (np.arange(n, dtype=np.uint32) // 2).astype(np.uint32)
+    n_units = int(uid[-1]) + 1
+    want = oracle.filter_batch(oidx, b, o, uid, threads=2)
+    gap = uid.copy()
+    gap[2000:] += 1                                  # unit 1000 has no read: its first-read entry would be a stale one
+    bad_ids = {
+        "beyond the units": uid + np.uint32(n_units),
+        "leftovers": rng.integers(0, 2**32 - 1, n, dtype=np.uint32),
+        "decreasing": uid[::-1].copy(),
+        "a unit without a read": np.minimum(gap, np.uint32(n_units - 1)),
+        "does not start at 0": np.maximum(uid, np.uint32(1)),
+        "stops short": np.minimum(uid, np.uint32(n_units - 2)),
+    }
+    d_uid = torch.from_numpy(uid.view(np.int32)).to(dev)
+    for name, arr in bad_ids.items():
+        d_bad = torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        proc.filter_batch_device(d_b.data_ptr(), d_good.data_ptr(), n, len(b), d_k.data_ptr(), d_h.data_ptr(), d_t.data_ptr(),
+                                 d_unit_id=d_bad.data_ptr(), n_units=n_units)
+        with pytest.raises(dcn.DeaconHipError) as e:
+            proc.synchronize()
+        assert e.value.code == dcn._native.DCN_ERR_ARG, name
+        proc.reset_stats()
+        proc.filter_batch_device(d_b.data_ptr(), d_good.data_ptr(), n, len(b), d_k.data_ptr(), d_h.data_ptr(), d_t.data_ptr(),
+                                 d_unit_id=d_uid.data_ptr(), n_units=n_units)
+        proc.synchronize()
+        assert d_k.cpu().numpy()[:n_units].astype(bool).tolist() == want[0].tolist(), name
+        assert d_h.cpu().numpy()[:n_units].tolist() == want[1].tolist(), name
+        assert d_t.cpu().numpy()[:n_units].tolist() == want[2].tolist(), name
+        assert proc.stats()["total_seqs"] == n and proc.stats()["total_bp"] == len(b), name
     proc.close()
 
 
